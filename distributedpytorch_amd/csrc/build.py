@@ -1,0 +1,108 @@
+"""In-tree native build: hipcc cross-compiles every kernel for gfx950 (no GPU needed) and g++ builds
+the host runtime.  Outputs land next to the package so they travel with the source tree:
+
+  distributedpytorch_amd/lib/libdpamd_hip.so   HIP/CDNA4 kernels (C ABI, loaded with ctypes)
+  distributedpytorch_amd/lib/libdpamd_host.so  C++ host runtime (sampler, IDX reader, bucket planner,
+                                               TCP rendezvous store) - no HIP dependency
+
+Usage: python -m distributedpytorch_amd.csrc.build [--force] [--jobs N]
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(HERE, "build")
+ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+ARCH = "gfx950"
+
+HIP_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffast-math", "-fno-gpu-rdc",
+             "-Wno-unused-result", "-DNDEBUG"]
+HOST_FLAGS = ["-O2", "-fPIC", "-std=c++17", "-Wall", "-pthread"]
+
+
+def _sources(sub, exts):
+    d = os.path.join(HERE, sub)
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def _deps_hash(src, extra):
+    h = hashlib.sha1()
+    for f in [src] + extra:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _compile(cmd, src, obj, stamp, digest):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"compile failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as fh:
+        fh.write(digest)
+    return src, r.stderr
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs = jobs or min(8, os.cpu_count() or 4)
+    hip_src = _sources("hip", (".hip",))
+    hip_hdr = _sources("hip", (".h",))
+    host_src = _sources("host", (".cpp",))
+    host_hdr = _sources("host", (".h",))
+    tasks = []
+    objs = {"hip": [], "host": []}
+    for kind, srcs, hdrs in (("hip", hip_src, hip_hdr), ("host", host_src, host_hdr)):
+        for src in srcs:
+            base = os.path.splitext(os.path.basename(src))[0]
+            obj = os.path.join(OBJDIR, f"{kind}_{base}.o")
+            stamp = obj + ".sha1"
+            digest = _deps_hash(src, hdrs)
+            objs[kind].append(obj)
+            if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+                continue
+            if kind == "hip":
+                cmd = [HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj]
+            else:
+                cmd = ["g++"] + HOST_FLAGS + ["-c", src, "-o", obj]
+            tasks.append((cmd, src, obj, stamp, digest))
+    relink = bool(tasks) or force
+    if tasks:
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for src, err in ex.map(lambda t: _compile(*t), tasks):
+                if verbose:
+                    print(f"[build] compiled {os.path.relpath(src, PKG)}", flush=True)
+                    if err.strip():
+                        print(err, file=sys.stderr)
+    hip_so = os.path.join(LIBDIR, "libdpamd_hip.so")
+    host_so = os.path.join(LIBDIR, "libdpamd_host.so")
+    if objs["hip"] and (relink or not os.path.exists(hip_so)):
+        # No rpath on purpose: libamdhip64.so.7 resolves to the copy torch has already loaded, so the
+        # kernels and torch share ONE HIP runtime (streams/events/pointers are interchangeable).
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", hip_so] + objs["hip"]
+        subprocess.run(cmd, check=True)
+        if verbose:
+            print(f"[build] linked {os.path.relpath(hip_so, PKG)}", flush=True)
+    if objs["host"] and (relink or not os.path.exists(host_so)):
+        cmd = ["g++", "-shared", "-fPIC", "-pthread", "-o", host_so] + objs["host"]
+        subprocess.run(cmd, check=True)
+        if verbose:
+            print(f"[build] linked {os.path.relpath(host_so, PKG)}", flush=True)
+    return hip_so, host_so
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.jobs)

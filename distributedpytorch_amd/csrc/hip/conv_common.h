@@ -1,0 +1,73 @@
+// Implicit-GEMM convolution on gfx950 MFMA: shared parameter block + LDS/MFMA helpers.
+//
+// Data layout (MI355X-first, not the reference's NCHW): activations are NHWC with the channel dimension
+// contiguous, weights are [Cout][kh][kw][Cin] ("KRSC"), so the GEMM reduction index (kh,kw,cin) is
+// contiguous in 16-byte chunks for BOTH operands and every global load / LDS access is 16 B per lane.
+// A tensor may be a channel slice of a wider buffer (channel stride `cs`, channel offset `co`): that is how
+// concat (SqueezeNet Fire, DenseNet, Inception) is done zero-copy (K12 of SURVEY.md §2.5).
+//
+// LDS image (both operands, both dtypes): rows of 128 bytes = 8 chunks of 16 B (64 bf16 or 32 fp32 of the
+// reduction dim), chunk index XOR-swizzled with (row>>1)&7 so that ds_write_b128 (8 lanes = one row) and
+// the ds_read_b128 fragment reads of mfma 16x16 (lane -> row l&15, chunk l>>4) are bank-conflict-free.
+#pragma once
+#include "common.h"
+
+struct FastDiv {  // n / d for 0 <= n < 2^31, d >= 1 : q = mulhi(n, mul) >> shift
+  uint32_t mul, shift, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f; f.d = d;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t l = 0; while ((1u << l) < d) ++l;           // ceil(log2 d)
+  uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+  f.mul = (uint32_t)m; f.shift = l; return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  uint32_t t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
+struct ConvParams {
+  const void* src;   // gathered operand: x (fprop) or dy (dgrad)            [sN, sH, sW, s_cs] (+s_co)
+  const void* wgt;   // [dC][R][S][sC] reduction-contiguous filter (fprop: W ; dgrad: W transposed)
+  void* dst;         // y (fprop) or dx (dgrad)                              [sN, dH, dW, d_cs] (+d_co)
+  const float* bias; // [dC] or null
+  float* stats;      // [gridM][2][dC] per-block (sum, sumsq) slab of the fp32 accumulators, or null
+  const void* addend; // optional tensor with dst geometry added in the epilogue (dgrad accumulation) or null
+  int sN, sH, sW, sC, s_cs, s_co;
+  int dH, dW, dC, d_cs, d_co;
+  int R, S, sh, sw, ph, pw;
+  int M;             // sN*dH*dW
+  int Kg;            // R*S*sC
+  int relu;          // apply max(.,0) in the epilogue
+  int tilesM, tilesN;
+  FastDiv fd_dW, fd_dH, fd_sC, fd_S;
+};
+
+template <typename T> struct MfmaT;
+template <> struct MfmaT<bf16_t> {
+  // one 16-byte chunk = 8 bf16 = one 16x16x32 k-quarter per lane
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct MfmaT<float> {
+  // one 16-byte chunk = 4 fp32 -> four exact-f32 16x16x4 MFMAs (k slot l>>4 <-> element t of the chunk,
+  // the same bijection on both operands, so the sum over k is unchanged)
+  static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// XCD-aware, bijective remap of the linear block id: blocks that share an XCD (id % 8) get a contiguous
+// run of tiles, so neighbouring tiles (which share activation rows / filter panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}

@@ -1,0 +1,286 @@
+// Implicit-GEMM convolution forward (fprop) and data-gradient (dgrad) for gfx950 (K1/K2 of SURVEY.md §2.5;
+// replaces the cuDNN convolutions the reference reaches through torchvision models at
+// /root/reference/classif.py:55,59 and utils.py:45-91).
+//
+//   GEMM view:  D[m][n] = sum_k A[m][k] * B[n][k]
+//     fprop : m = (img, ho, wo)  n = cout  k = (r, s, cin)   A = im2col(x) gathered on the fly, B = W[cout][r][s][cin]
+//     dgrad : m = (img, hi, wi)  n = cin   k = (r, s, cout)  A = gathered dy (only taps with (hi+p-r) % stride == 0),
+//                                                             B = Wt[cin][r][s][cout]
+//   Block = 256 threads = 4 waves (WM x WN), each wave owns (TM*16) x (TN*16) of the output as TM x TN
+//   accumulators of mfma 16x16 (bf16: v_mfma_f32_16x16x32_bf16, fp32: exact v_mfma_f32_16x16x4_f32).
+//   K step = 128 bytes per row (64 bf16 / 32 fp32).  Register-staged software pipeline: the global loads of
+//   K-tile t+1 are issued before the MFMAs of tile t and written to LDS after the barrier.
+//   Epilogue (fused): + bias, + addend, ReLU, per-channel (sum, sumsq) slab for BatchNorm statistics, and the
+//   tile is staged through LDS so global stores are 16 B per lane along the channel dimension, at an
+//   arbitrary channel offset/stride of the destination buffer (zero-copy concat).
+#include "conv_common.h"
+
+template <typename T, int WM, int WN, int TM, int TN, bool DGRAD>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
+  constexpr int BKE = 8 * VEC;               // reduction elements per K-tile (128-byte rows)
+  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+  static_assert(WM * WN == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;
+  char* ldsB = smem + BM * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+
+  // ---- per-thread gather state: this thread stages chunk `ck` of rows (tid>>3) + 32*i -----------------
+  const int ck = tid & 7;
+  const int row0 = tid >> 3;
+  uint32_t a_base[A_PASSES];   // element offset of (img, 0, 0, s_co) in src; 0xffffffff when the row is out of range
+  int a_y0[A_PASSES], a_x0[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    if (m < p.M) {
+      const uint32_t t1 = fd_div((uint32_t)m, p.fd_dW);
+      const int xo = m - (int)t1 * p.dW;
+      const uint32_t img = fd_div(t1, p.fd_dH);
+      const int yo = (int)t1 - (int)img * p.dH;
+      a_base[i] = img * (uint32_t)(p.sH * p.sW) ;
+      if (DGRAD) { a_y0[i] = yo + p.ph; a_x0[i] = xo + p.pw; }
+      else       { a_y0[i] = yo * p.sh - p.ph; a_x0[i] = xo * p.sw - p.pw; }
+    } else {
+      a_base[i] = 0xffffffffu; a_y0[i] = 0; a_x0[i] = 0;
+    }
+  }
+  uint32_t b_base[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int n = n0 + row0 + 32 * i;
+    b_base[i] = (n < p.dC) ? (uint32_t)n * (uint32_t)p.Kg : 0xffffffffu;
+  }
+
+  uint4 ra[A_PASSES], rb[B_PASSES];
+  auto load_tile = [&](int kt) {
+    const int kidx = kt * BKE + ck * VEC;
+    const bool kin = kidx < p.Kg;
+    const uint32_t tap = fd_div((uint32_t)kidx, p.fd_sC);
+    const int c = kidx - (int)tap * p.sC;
+    const int r = (int)fd_div(tap, p.fd_S);
+    const int s = (int)tap - r * p.S;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      int sy, sx; bool ok = kin && (a_base[i] != 0xffffffffu);
+      if (DGRAD) {
+        const int ty = a_y0[i] - r, tx = a_x0[i] - s;
+        if (p.sh == 1 && p.sw == 1) { sy = ty; sx = tx; }
+        else {
+          sy = ty / p.sh; sx = tx / p.sw;   // ty,tx may be negative: checked below before use
+          ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.sh == ty) && (sx * p.sw == tx);
+        }
+      } else { sy = a_y0[i] + r; sx = a_x0[i] + s; }
+      ok = ok && ((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const size_t off = ((size_t)a_base[i] + (size_t)(sy * p.sW + sx)) * (size_t)p.s_cs + (size_t)(p.s_co + c);
+        v = *reinterpret_cast<const uint4*>(src + off);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kin && b_base[i] != 0xffffffffu) v = *reinterpret_cast<const uint4*>(wgt + (size_t)b_base[i] + kidx);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<uint4*>(ldsA + lds_off(row0 + 32 * i, ck)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) *reinterpret_cast<uint4*>(ldsB + lds_off(row0 + 32 * i, ck)) = rb[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (p.Kg + BKE - 1) / BKE;
+  const int fr = lane & 15, fq = lane >> 4;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const uint4*>(ldsA + lds_off(wm * TM * 16 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const uint4*>(ldsB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MfmaT<T>::mma(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---------------------------------------- epilogue --------------------------------------------------
+  // acc[i][j][e] = D[row = wm*TM*16 + i*16 + fq*4 + e][col = wn*TN*16 + j*16 + fr]
+  T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
+  const T* __restrict__ addend = reinterpret_cast<const T*>(p.addend);
+  constexpr int WCOLS = TN * 16;               // columns owned by a wave
+  constexpr int PITCH = WCOLS + 4;             // floats; keeps ds_write_b32 conflict-free and rows 16-B aligned
+  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * PITCH);
+  float* red = reinterpret_cast<float*>(smem) + 4 * 16 * PITCH;   // [WM][2][BN] cross-wave stats scratch
+
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+
+  float bj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WCOLS + j * 16 + fr;
+    bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
+  }
+  constexpr int LPR = WCOLS / VEC;             // lanes per output row (16-B chunks per row)
+  constexpr int RPI = 64 / LPR;                // rows per store instruction
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    // wave-private staging region: no block barrier needed between iterations, only LDS ordering
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[i][j][e] + bj[j];
+        stage[(fq * 4 + e) * PITCH + j * 16 + fr] = v;
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += RPI) {
+      const int r = rr + lane / LPR;
+      const int cc = (lane % LPR) * VEC;
+      const int m = m0 + wm * TM * 16 + i * 16 + r;
+      const int col = n0 + wn * WCOLS + cc;
+      float v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc + e]);
+        v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+      }
+      if (m < p.M && col < p.dC) {
+        const size_t off = (size_t)m * (size_t)p.d_cs + (size_t)(p.d_co + col);
+        if (addend) {
+          Vec16<T> av; av.load(addend + off);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] += av.get(e);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        Vec16<T> ov;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ov.set(e, v[e]);
+        ov.store(dst + off);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (p.stats) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
+          float v = acc[i][j][e] + bj[j];
+          if (sizeof(T) == 2) v = bf2f(f2bf(v));   // statistics of the values as stored
+          if (m >= p.M) v = 0.f;
+          csum[j] += v; csq[j] += v * v;
+        }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();                             // staging region is reused below (block-wide)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j], q = csq[j];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (fq == 0) {
+        red[(wm * 2 + 0) * BN + wn * WCOLS + j * 16 + fr] = s;
+        red[(wm * 2 + 1) * BN + wn * WCOLS + j * 16 + fr] = q;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int which = c / BN, col = c - which * BN;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
+      if (n0 + col < p.dC) p.stats[((size_t)tm * 2 + which) * p.dC + n0 + col] = s;
+    }
+  }
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
+  ConvParams p = pin;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  p.tilesM = (p.M + BM - 1) / BM;
+  p.tilesN = (p.dC + BN - 1) / BN;
+  size_t lds = (size_t)(BM + BN) * 128;
+  size_t epi = (size_t)(4 * 16 * (TN * 16 + 4) + WM * 2 * BN) * 4;
+  if (epi > lds) lds = epi;
+  dim3 grid(p.tilesM * p.tilesN), block(256);
+  if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true>), grid, block, lds, s, p);
+  else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false>), grid, block, lds, s, p);
+}
+
+template <typename T>
+static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
+  p.M = p.sN * p.dH * p.dW;
+  p.Kg = p.R * p.S * p.sC;
+  constexpr int VEC = 16 / sizeof(T);
+  if (p.sC % VEC || p.s_cs % VEC || p.s_co % VEC || p.dC % VEC || p.d_cs % VEC || p.d_co % VEC) return 1;
+  if ((size_t)p.sN * p.sH * p.sW >= 0x7fffffffull || (size_t)p.M >= 0x7fffffffull) return 2;
+  p.fd_dW = make_fastdiv(p.dW); p.fd_dH = make_fastdiv(p.dH);
+  p.fd_sC = make_fastdiv(p.sC); p.fd_S = make_fastdiv(p.S);
+  // tile selection: narrow outputs get a tall tile; small problems get small tiles so that the grid
+  // still covers the 256 CUs.
+  const long long big_tiles = (long long)((p.M + 127) / 128) * ((p.dC + 127) / 128);
+  if (p.dC <= 32)                     launch_cfg<T, 4, 1, 2, 2>(p, dgrad, s);   // 128 x 32
+  else if (p.dC <= 64) {
+    if ((p.M + 255) / 256 >= 256)     launch_cfg<T, 4, 1, 4, 4>(p, dgrad, s);   // 256 x 64
+    else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
+  } else if (big_tiles >= 384)        launch_cfg<T, 2, 2, 4, 4>(p, dgrad, s);   // 128 x 128
+  else                                launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
+  return 0;
+}
+
+// dtype: 0 = fp32, 1 = bf16.  Returns 0 on success, non-zero for an unsupported geometry.
+DPA_API int dpa_conv_igemm(ConvParams* p, int dtype, int dgrad, hipStream_t s) {
+  ConvParams q = *p;
+  return dtype == 1 ? launch_conv<bf16_t>(q, dgrad, s) : launch_conv<float>(q, dgrad, s);
+}
+// rows of the per-block stats slab a launch with these dims will write (tilesM of the chosen config)
+DPA_API int dpa_conv_stats_rows(int M, int dC) {
+  const long long big_tiles = (long long)((M + 127) / 128) * ((dC + 127) / 128);
+  if (dC <= 32) return (M + 127) / 128;
+  if (dC <= 64) return ((M + 255) / 256 >= 256) ? (M + 255) / 256 : (M + 63) / 64;
+  return big_tiles >= 384 ? (M + 127) / 128 : (M + 63) / 64;
+}
+DPA_API int dpa_conv_params_size() { return (int)sizeof(ConvParams); }

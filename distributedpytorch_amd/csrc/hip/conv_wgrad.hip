@@ -1,0 +1,267 @@
+// Implicit-GEMM convolution weight-gradient for gfx950 (K3 of SURVEY.md §2.5; replaces cuDNN wgrad reached
+// from loss.backward() at /root/reference/classif.py:59).
+//
+//   dW[k][r][s][c] = sum_{img,ho,wo} dy[img,ho,wo,k] * x[img, ho*sh-ph+r, wo*sw-pw+s, c]
+//   GEMM view: D[m = k][n = (r,s,c)] = sum_{pix} A[pix][m] * B[pix][n]   -- the reduction index (pixel) is the
+//   STRIDED dimension of both operands, so tiles are staged pixel-major ([pix][channels], 16 B per lane) and
+//   the MFMA fragments are read transposed out of LDS: ds_read_b64_tr_b16 for bf16 (gfx950 hardware
+//   transpose), plain ds_read_b32 for the exact-fp32 16x16x4 MFMA (one float per lane per operand).
+//   The output is tiny and the reduction is huge (up to N*112*112 pixels), so the grid is split over the
+//   pixel dimension (split-K) into fp32 partial slabs that a deterministic second kernel sums (no float
+//   atomics: bitwise reproducible, cdna_hip_programming.md Guideline 12).
+#include "conv_common.h"
+
+struct WgradParams {
+  const void* dy;    // [N, Ho, Wo, k_cs] (+k_co)   Cout = K
+  const void* x;     // [N, H, W, c_cs] (+c_co)     Cin = C
+  float* out;        // splitK == 1: dW [K][R][S][C] fp32 ; else slabs [splitK][K][R*S*C]
+  int N, H, W, C, c_cs, c_co;
+  int Ho, Wo, K, k_cs, k_co;
+  int R, S, sh, sw, ph, pw;
+  int P;             // N*Ho*Wo pixels (reduction length)
+  int Ng;            // R*S*C
+  int tilesM, tilesN, splitK, pixPerSplit;
+  int accumulate;    // splitK == 1 only: out += result
+  FastDiv fd_Wo, fd_Ho, fd_C, fd_S;
+};
+
+template <typename T> struct WgLds;
+template <> struct WgLds<bf16_t> { static constexpr int PAD = 32; };   // bytes; shifts each pixel row by 8 banks
+template <> struct WgLds<float>  { static constexpr int PAD = 64; };   // (pitch/4) % 32 == 16
+
+template <typename T, int TM, int TN>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams p) {
+  constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int BKP = 8 * VEC;                          // pixels per K-tile (64 bf16 / 32 fp32)
+  constexpr int PITCH_A = BM * sizeof(T) + WgLds<T>::PAD;
+  constexpr int PITCH_B = BN * sizeof(T) + WgLds<T>::PAD;
+  constexpr int CPR_A = BM / VEC, CPR_B = BN / VEC;     // 16-byte chunks per pixel row
+  constexpr int A_PASSES = BKP * CPR_A / 256, B_PASSES = BKP * CPR_B / 256;
+  constexpr int RPP_A = 256 / CPR_A, RPP_B = 256 / CPR_B;   // pixel rows per pass
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;
+  char* ldsB = smem + BKP * PITCH_A;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int tilesMN = p.tilesM * p.tilesN;
+  const int z = bid / tilesMN;
+  bid -= z * tilesMN;
+  const int tm = bid / p.tilesN, tn = bid - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int pix_begin = z * p.pixPerSplit;
+  const int pix_end = min(p.P, pix_begin + p.pixPerSplit);
+
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+
+  // A operand (dy): this thread stages chunk ca of pixel rows ra0 + RPP_A*i
+  const int ca = tid % CPR_A, ra0 = tid / CPR_A;
+  const int a_col = m0 + ca * VEC;
+  const bool a_ok = a_col < p.K;
+  // B operand (x gathered): chunk cb -> fixed (r, s, c) for the whole reduction
+  const int cb = tid % CPR_B, rb0 = tid / CPR_B;
+  const int nidx = n0 + cb * VEC;
+  const bool b_ok = nidx < p.Ng;
+  const uint32_t tap = fd_div((uint32_t)(b_ok ? nidx : 0), p.fd_C);
+  const int bc = (b_ok ? nidx : 0) - (int)tap * p.C;
+  const int br = (int)fd_div(tap, p.fd_S);
+  const int bs = (int)tap - br * p.S;
+
+  uint4 ra[A_PASSES], rb[B_PASSES];
+  auto load_tile = [&](int pix0) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int pix = pix0 + ra0 + RPP_A * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_ok && pix < pix_end) v = *reinterpret_cast<const uint4*>(dy + (size_t)pix * p.k_cs + p.k_co + a_col);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int pix = pix0 + rb0 + RPP_B * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_ok && pix < pix_end) {
+        const uint32_t t1 = fd_div((uint32_t)pix, p.fd_Wo);
+        const int wo = pix - (int)t1 * p.Wo;
+        const uint32_t img = fd_div(t1, p.fd_Ho);
+        const int ho = (int)t1 - (int)img * p.Ho;
+        const int hi = ho * p.sh - p.ph + br, wi = wo * p.sw - p.pw + bs;
+        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+          const size_t off = ((size_t)img * (p.H * p.W) + (size_t)(hi * p.W + wi)) * p.c_cs + p.c_co + bc;
+          v = *reinterpret_cast<const uint4*>(x + off);
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      *reinterpret_cast<uint4*>(ldsA + (ra0 + RPP_A * i) * PITCH_A + ca * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i)
+      *reinterpret_cast<uint4*>(ldsB + (rb0 + RPP_B * i) * PITCH_B + cb * 16) = rb[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  if (pix_begin < pix_end) {
+    load_tile(pix_begin);
+    store_tile();
+    __syncthreads();
+    for (int pix0 = pix_begin; pix0 < pix_end; pix0 += BKP) {
+      const bool more = pix0 + BKP < pix_end;
+      if (more) load_tile(pix0 + BKP);
+      if constexpr (sizeof(T) == 2) {
+        // bf16: per 32-pixel k-step, lane needs k = 8*fq + j (j = 0..7) of column fr: two transposed
+        // 4x16 block reads; lane (4q+pp) of each 16-lane group addresses block row q, columns 4pp..4pp+3.
+        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+        const int q = fr >> 2, pp = fr & 3;
+#pragma unroll
+        for (int ks = 0; ks < BKP / 32; ++ks) {
+          bf16x8 fa[TM], fb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int col = (wm * TM * 16 + i * 16 + 4 * pp) * 2;
+            const int krow = ks * 32 + 8 * fq + q;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsA + krow * PITCH_A + col));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsA + (krow + 4) * PITCH_A + col));
+            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN * 16 + j * 16 + 4 * pp) * 2;
+            const int krow = ks * 32 + 8 * fq + q;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsB + krow * PITCH_B + col));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsB + (krow + 4) * PITCH_B + col));
+            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+        // fp32: 16x16x4, lane holds A[m = fr][k = fq] = tile[k][m]
+#pragma unroll
+        for (int ks = 0; ks < BKP / 4; ++ks) {
+          float fa[TM], fb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            fa[i] = *reinterpret_cast<const float*>(ldsA + (ks * 4 + fq) * PITCH_A + (wm * TM * 16 + i * 16 + fr) * 4);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            fb[j] = *reinterpret_cast<const float*>(ldsB + (ks * 4 + fq) * PITCH_B + (wn * TN * 16 + j * 16 + fr) * 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (more) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+  }
+
+  // epilogue: D[row = m0 + wm*TM*16 + i*16 + fq*4 + e][col = n0 + wn*TN*16 + j*16 + fr]
+  float* out = p.out + (size_t)z * p.K * p.Ng;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 16 + j * 16 + fr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
+        if (row < p.K && col < p.Ng) {
+          float* o = out + (size_t)row * p.Ng + col;
+          *o = (p.accumulate && p.splitK == 1) ? (*o + acc[i][j][e]) : acc[i][j][e];
+        }
+      }
+    }
+}
+
+// Sum the split-K slabs in a fixed order (deterministic) into the gradient arena.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                           long long n, int splitK, int accumulate) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {   // n is a multiple of 4 (channel counts are multiples of 4)
+    float4 s = *reinterpret_cast<const float4*>(slabs + i);
+    for (int z = 1; z < splitK; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(out + i);
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
+  }
+}
+
+template <typename T, int TM, int TN>
+static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t s) {
+  constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16, VEC = 16 / sizeof(T), BKP = 8 * VEC;
+  p.tilesM = (p.K + BM - 1) / BM;
+  p.tilesN = (p.Ng + BN - 1) / BN;
+  const int tiles = p.tilesM * p.tilesN;
+  const int ksteps = (p.P + BKP - 1) / BKP;
+  int split = (1024 + tiles - 1) / tiles;
+  if (split > ksteps / 4) split = ksteps / 4;
+  if (split < 1) split = 1;
+  if (!workspace) split = 1;
+  int steps_per = (ksteps + split - 1) / split;
+  split = (ksteps + steps_per - 1) / steps_per;
+  p.splitK = split;
+  p.pixPerSplit = steps_per * BKP;
+  p.out = split == 1 ? grad : workspace;
+  size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
+  if (split > 1) {
+    const long long n = (long long)p.K * p.Ng;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dpa_grid((n + 3) / 4, 256)), dim3(256), 0, s, workspace, grad, n,
+                       split, p.accumulate);
+  }
+}
+
+template <typename T>
+static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_t s) {
+  constexpr int VEC = 16 / sizeof(T);
+  p.P = p.N * p.Ho * p.Wo;
+  p.Ng = p.R * p.S * p.C;
+  if (p.C % VEC || p.c_cs % VEC || p.c_co % VEC || p.K % VEC || p.k_cs % VEC || p.k_co % VEC) return 1;
+  if ((size_t)p.N * p.H * p.W >= 0x7fffffffull || (size_t)p.P >= 0x7fffffffull) return 2;
+  p.fd_Wo = make_fastdiv(p.Wo); p.fd_Ho = make_fastdiv(p.Ho);
+  p.fd_C = make_fastdiv(p.C); p.fd_S = make_fastdiv(p.S);
+  if (p.K <= 64 || p.Ng <= 64) wg_launch<T, 2, 2>(p, grad, workspace, s);
+  else                         wg_launch<T, 4, 4>(p, grad, workspace, s);
+  return 0;
+}
+
+// workspace: fp32 scratch of at least dpa_conv_wgrad_workspace() floats, or null to force splitK = 1.
+DPA_API int dpa_conv_wgrad(WgradParams* p, float* grad, float* workspace, int dtype, hipStream_t s) {
+  WgradParams q = *p;
+  return dtype == 1 ? wg_dispatch<bf16_t>(q, grad, workspace, s) : wg_dispatch<float>(q, grad, workspace, s);
+}
+// upper bound on workspace floats for a layer: split <= 1024 tiles-worth, i.e. <= ~1024*BM*BN + K*Ng
+DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {
+  const int bm = (K <= 64 || Ng <= 64) ? 64 : 128;
+  const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bm - 1) / bm);
+  long long split = (1024 + tiles - 1) / tiles;
+  return split * (long long)K * Ng;
+}
+DPA_API int dpa_wgrad_params_size() { return (int)sizeof(WgradParams); }

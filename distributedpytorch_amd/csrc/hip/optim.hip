@@ -1,0 +1,114 @@
+// Fused multi-tensor optimizer kernels over flat fp32 arenas (K17/K18/K18b of SURVEY.md §2.5).
+// Reference behaviour: torch.optim.Adam(lr=1e-3) / SGD(lr=1e-3, momentum=0.9) as selected at
+// /root/reference/classif.py:123-128.  All parameters live in ONE contiguous arena, so a whole model
+// (or one gradient bucket of it) is updated by a single launch: 16 B/lane vector access, grid-stride.
+// Hyper-parameters and the step counter live in device memory so that a captured hipGraph replays
+// correctly when lr (StepLR) or the step changes.
+#include "common.h"
+
+// hyper layout (floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step (as float)
+//                        [6]=momentum [7]=grad_scale (1/world_size folded in here)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ p16, const float* __restrict__ hyper,
+                                                   long long n) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float step = hyper[5] + 1.0f, gs = hyper[7];
+  const float bc1 = 1.0f - powf(b1, step);
+  const float bc2s = sqrtf(1.0f - powf(b2, step));
+  const float step_size = lr / bc1;
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 pp = *reinterpret_cast<float4*>(p + i);
+    float4 gg = *reinterpret_cast<const float4*>(g + i);
+    float4 mm = *reinterpret_cast<float4*>(m + i);
+    float4 vv = *reinterpret_cast<float4*>(v + i);
+    float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gr = ga[k] * gs + wd * pa[k];
+      ma[k] = b1 * ma[k] + (1.0f - b1) * gr;
+      va[k] = b2 * va[k] + (1.0f - b2) * gr * gr;
+      float denom = sqrtf(va[k]) / bc2s + eps;
+      pa[k] -= step_size * (ma[k] / denom);
+    }
+    *reinterpret_cast<float4*>(p + i) = pp;
+    *reinterpret_cast<float4*>(m + i) = mm;
+    *reinterpret_cast<float4*>(v + i) = vv;
+    if (p16) {
+      uint2 o;
+      o.x = (uint32_t)f2bf(pa[0]) | ((uint32_t)f2bf(pa[1]) << 16);
+      o.y = (uint32_t)f2bf(pa[2]) | ((uint32_t)f2bf(pa[3]) << 16);
+      *reinterpret_cast<uint2*>(p16 + i) = o;
+    }
+  }
+  // tail (n not multiple of 4): handled by the thread whose i lands on it
+  if (i < n) {
+    for (long long j = i; j < n; ++j) {
+      float gr = g[j] * gs + wd * p[j];
+      float mj = b1 * m[j] + (1.0f - b1) * gr;
+      float vj = b2 * v[j] + (1.0f - b2) * gr * gr;
+      m[j] = mj; v[j] = vj;
+      float pj = p[j] - step_size * (mj / (sqrtf(vj) / bc2s + eps));
+      p[j] = pj;
+      if (p16) p16[j] = f2bf(pj);
+    }
+  }
+}
+
+// torch SGD: buf = g on the first step, then buf = mu*buf + g ; p -= lr*buf  (dampening 0, no nesterov)
+__global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, bf16_t* __restrict__ p16,
+                                                  const float* __restrict__ hyper, long long n) {
+  const float lr = hyper[0], wd = hyper[4], mu = hyper[6], gs = hyper[7];
+  const bool first = hyper[5] < 0.5f;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float gr = g[i] * gs + wd * p[i];
+    float b = gr;
+    if (mu != 0.0f) {
+      b = first ? gr : mu * buf[i] + gr;
+      buf[i] = b;
+    }
+    float pj = p[i] - lr * b;
+    p[i] = pj;
+    if (p16) p16[i] = f2bf(pj);
+  }
+}
+
+__global__ void advance_step_kernel(float* hyper) { hyper[5] += 1.0f; }
+
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = f2bf(s[i]);
+}
+__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = bf2f(s[i]);
+}
+
+DPA_API void dpa_adam_step(float* p, const float* g, float* m, float* v, bf16_t* p16, const float* hyper,
+                           long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(adam_kernel, dim3(dpa_grid((n + 3) / 4, 256)), dim3(256), 0, s, p, g, m, v, p16, hyper, n);
+}
+DPA_API void dpa_sgd_step(float* p, const float* g, float* buf, bf16_t* p16, const float* hyper, long long n,
+                          hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(sgd_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, p, g, buf, p16, hyper, n);
+}
+DPA_API void dpa_advance_step(float* hyper, hipStream_t s) {
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, hyper);
+}
+DPA_API void dpa_cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, src, dst, n);
+}
+DPA_API void dpa_cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, src, dst, n);
+}

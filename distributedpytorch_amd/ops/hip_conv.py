@@ -1,0 +1,116 @@
+"""HIP implicit-GEMM convolution entry points (fprop / dgrad / wgrad) operating on NHWC torch tensors.
+
+Tensors are memory handles only: `x[N,H,W,C]` may be a channel slice of a wider NHWC buffer (stride(2) is the
+channel stride, stride(3) == 1), which is how concat is done without copies.  Filters are KRSC
+`[Cout, kh, kw, Cin]` contiguous.  See csrc/hip/conv_igemm.hip and conv_wgrad.hip.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import native
+from .native import ConvParams, WgradParams, VP
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _check_nhwc(t, name):
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError(f"{name}: expected NHWC tensor with contiguous channels, got strides {t.stride()}")
+    n, h, w, c = t.shape
+    cs = t.stride(2)
+    if (w > 1 and t.stride(1) != w * cs) or (h > 1 and t.stride(0) != h * w * cs and n > 1):
+        raise ValueError(f"{name}: only channel-sliced NHWC views are supported, got strides {t.stride()}")
+    if t.data_ptr() % 16:
+        raise ValueError(f"{name}: data pointer must be 16-byte aligned")
+    return cs
+
+
+def out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None):
+    """y = conv(x, w) (+bias) (+addend) (relu).  stats: fp32 [rows, 2, Cout] slab written with per-block
+    (sum, sumsq) of the stored outputs; rows = stats_rows(M, Cout)."""
+    lib = native.hip_lib()
+    sh, sw = stride
+    ph, pw = pad
+    p = ConvParams()
+    p.src, p.wgt, p.dst = VP(x.data_ptr()), VP(w.data_ptr()), VP(y.data_ptr())
+    p.bias = native.ptr(bias)
+    p.stats = native.ptr(stats)
+    p.addend = native.ptr(addend)
+    p.sN, p.sH, p.sW, p.sC = x.shape
+    p.s_cs, p.s_co = _check_nhwc(x, "x"), 0
+    p.dH, p.dW, p.dC = y.shape[1], y.shape[2], y.shape[3]
+    p.d_cs, p.d_co = _check_nhwc(y, "y"), 0
+    p.R, p.S = w.shape[1], w.shape[2]
+    p.sh, p.sw, p.ph, p.pw = sh, sw, ph, pw
+    p.relu = int(relu)
+    assert w.is_contiguous() and w.shape[0] == p.dC and w.shape[3] == p.sC, (w.shape, x.shape, y.shape)
+    assert x.dtype == w.dtype == y.dtype
+    if addend is not None:
+        assert addend.stride() == y.stride()
+    rc = lib.dpa_conv_igemm(ctypes.byref(p), _DT[x.dtype], 0, native.stream_ptr())
+    if rc:
+        raise RuntimeError(f"dpa_conv_igemm(fprop) rejected geometry rc={rc}: x{tuple(x.shape)} w{tuple(w.shape)}")
+    return y
+
+
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None):
+    """dx = conv_transpose(dy, w).  wt is the filter transposed to [Cin, kh, kw, Cout] (reduction-contiguous).
+    addend (same geometry as dx) is added in the epilogue (gradient accumulation for fan-out)."""
+    lib = native.hip_lib()
+    sh, sw = stride
+    ph, pw = pad
+    p = ConvParams()
+    p.src, p.wgt, p.dst = VP(dy.data_ptr()), VP(wt.data_ptr()), VP(dx.data_ptr())
+    p.bias, p.stats, p.addend = VP(0), VP(0), native.ptr(addend)
+    p.sN, p.sH, p.sW, p.sC = dy.shape
+    p.s_cs, p.s_co = _check_nhwc(dy, "dy"), 0
+    p.dH, p.dW, p.dC = dx.shape[1], dx.shape[2], dx.shape[3]
+    p.d_cs, p.d_co = _check_nhwc(dx, "dx"), 0
+    p.R, p.S = wt.shape[1], wt.shape[2]
+    p.sh, p.sw, p.ph, p.pw = sh, sw, ph, pw
+    p.relu = 0
+    assert wt.is_contiguous() and wt.shape[0] == p.dC and wt.shape[3] == p.sC
+    if addend is not None:
+        assert addend.stride() == dx.stride()
+    rc = lib.dpa_conv_igemm(ctypes.byref(p), _DT[dy.dtype], 1, native.stream_ptr())
+    if rc:
+        raise RuntimeError(f"dpa_conv_igemm(dgrad) rejected geometry rc={rc}")
+    return dx
+
+
+def wgrad_workspace_numel(cout, rsc):
+    return int(native.hip_lib().dpa_conv_wgrad_workspace(cout, rsc))
+
+
+def conv_wgrad(dy, x, dw, ksize, stride, pad, workspace=None, accumulate=False):
+    """dw[Cout,kh,kw,Cin] (fp32) = sum over pixels of dy (x) im2col(x).  workspace: fp32 scratch for split-K."""
+    lib = native.hip_lib()
+    p = WgradParams()
+    p.dy, p.x, p.out = VP(dy.data_ptr()), VP(x.data_ptr()), VP(0)
+    p.N, p.H, p.W, p.C = x.shape
+    p.c_cs, p.c_co = _check_nhwc(x, "x"), 0
+    p.Ho, p.Wo, p.K = dy.shape[1], dy.shape[2], dy.shape[3]
+    p.k_cs, p.k_co = _check_nhwc(dy, "dy"), 0
+    p.R, p.S = ksize
+    p.sh, p.sw = stride
+    p.ph, p.pw = pad
+    p.accumulate = int(accumulate)
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == p.K * p.R * p.S * p.C
+    if workspace is not None:
+        assert workspace.dtype == torch.float32 and workspace.numel() >= wgrad_workspace_numel(p.K, p.R * p.S * p.C)
+    rc = lib.dpa_conv_wgrad(ctypes.byref(p), VP(dw.data_ptr()), native.ptr(workspace), _DT[x.dtype],
+                            native.stream_ptr())
+    if rc:
+        raise RuntimeError(f"dpa_conv_wgrad rejected geometry rc={rc}")
+    return dw
+
+
+def stats_rows(m, cout):
+    return int(native.hip_lib().dpa_conv_stats_rows(int(m), int(cout)))

@@ -1,0 +1,103 @@
+"""ctypes bindings to the in-tree native libraries.
+
+libdpamd_hip.so   hand-written gfx950 kernels (C ABI; pointers + hipStream_t)
+libdpamd_host.so  C++ host runtime (sampler, IDX reader, bucket planner, TCP store)
+
+torch must be imported before the HIP library is loaded: the library links `libamdhip64.so.7` without an
+rpath, so the dynamic loader binds it to the HIP runtime torch has already mapped and both share one
+runtime (streams, events and device pointers are interchangeable).  On a machine with a GPU a missing
+library is a hard error - there is no silent eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL of the HIP library)
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
+_hip = None
+_host = None
+
+VP = ctypes.c_void_p
+I32 = ctypes.c_int
+I64 = ctypes.c_longlong
+F32 = ctypes.c_float
+
+
+class FastDiv(ctypes.Structure):
+    _fields_ = [("mul", ctypes.c_uint32), ("shift", ctypes.c_uint32), ("d", ctypes.c_uint32)]
+
+
+class ConvParams(ctypes.Structure):
+    _fields_ = [
+        ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP),
+        ("sN", I32), ("sH", I32), ("sW", I32), ("sC", I32), ("s_cs", I32), ("s_co", I32),
+        ("dH", I32), ("dW", I32), ("dC", I32), ("d_cs", I32), ("d_co", I32),
+        ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),
+        ("M", I32), ("Kg", I32), ("relu", I32), ("tilesM", I32), ("tilesN", I32),
+        ("fd_dW", FastDiv), ("fd_dH", FastDiv), ("fd_sC", FastDiv), ("fd_S", FastDiv),
+    ]
+
+
+class WgradParams(ctypes.Structure):
+    _fields_ = [
+        ("dy", VP), ("x", VP), ("out", VP),
+        ("N", I32), ("H", I32), ("W", I32), ("C", I32), ("c_cs", I32), ("c_co", I32),
+        ("Ho", I32), ("Wo", I32), ("K", I32), ("k_cs", I32), ("k_co", I32),
+        ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),
+        ("P", I32), ("Ng", I32), ("tilesM", I32), ("tilesN", I32), ("splitK", I32), ("pixPerSplit", I32),
+        ("accumulate", I32),
+        ("fd_Wo", FastDiv), ("fd_Ho", FastDiv), ("fd_C", FastDiv), ("fd_S", FastDiv),
+    ]
+
+
+def lib_path(name: str) -> str:
+    return os.path.join(_LIBDIR, name)
+
+
+def hip_lib():
+    """The HIP kernel library; raises if it has not been built (python -m distributedpytorch_amd.csrc.build)."""
+    global _hip
+    if _hip is None:
+        path = lib_path("libdpamd_hip.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build the native kernels first with "
+                "`python -m distributedpytorch_amd.csrc.build` (the HIP path has no eager fallback)")
+        lib = ctypes.CDLL(path)
+        for fn in ("dpa_conv_params_size", "dpa_wgrad_params_size"):
+            getattr(lib, fn).restype = I32
+        if lib.dpa_conv_params_size() != ctypes.sizeof(ConvParams):
+            raise RuntimeError("ConvParams ABI mismatch between ops/native.py and conv_common.h")
+        if lib.dpa_wgrad_params_size() != ctypes.sizeof(WgradParams):
+            raise RuntimeError("WgradParams ABI mismatch between ops/native.py and conv_wgrad.hip")
+        lib.dpa_conv_wgrad_workspace.restype = I64
+        _hip = lib
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = lib_path("libdpamd_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m distributedpytorch_amd.csrc.build`")
+        _host = ctypes.CDLL(path)
+    return _host
+
+
+def have_hip_lib() -> bool:
+    return os.path.exists(lib_path("libdpamd_hip.so"))
+
+
+def have_host_lib() -> bool:
+    return os.path.exists(lib_path("libdpamd_host.so"))
+
+
+def stream_ptr() -> VP:
+    return VP(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> VP:
+    return VP(t.data_ptr()) if t is not None else VP(0)
