@@ -1,0 +1,306 @@
+// BatchNorm2d for NHWC activations on gfx950 (K5/K6/K7/K11 of SURVEY.md §2.5; the reference reaches these
+// through torchvision's BatchNorm2d layers, /root/reference/utils.py:45-91).
+//
+// Training forward is split so that the statistics pass costs no extra read of the activation:
+//   conv epilogue  -> per-block (sum, sumsq) slab        (conv_igemm.hip)       [or bn_stats for non-conv inputs]
+//   bn_finalize    -> mean / invstd / running stats / folded (scale, shift)     (tiny)
+//   bn_apply       -> y = relu?(x*scale + shift (+ residual))                   (one read, one write, 16 B/lane)
+// Backward:
+//   bn_bwd_reduce  -> dz = dy * (y > 0) written IN PLACE over dy, slab of (sum dz, sum dz*xhat)
+//   bn_bwd_finalize-> dgamma, dbeta
+//   bn_bwd_dx      -> dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M)
+// All slabs are reduced in a fixed order: results are bitwise reproducible (no float atomics).
+#include "common.h"
+
+#define ROWS_L2 32   // rows of the second-level slab
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, long long M, int C, int cs,
+                                                       float* __restrict__ slab, int rowsPerBlock) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[2][256][VEC > 4 ? 9 : 5];
+  const int cpr = C / VEC;
+  const int colsPerPass = cpr < 256 ? cpr : 256;
+  const int rowLanes = 256 / colsPerPass;
+  const int tid = threadIdx.x;
+  const int col = tid % colsPerPass, rl = tid / colsPerPass;
+  const long long r0 = (long long)blockIdx.x * rowsPerBlock;
+  long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
+  for (int cb = 0; cb < cpr; cb += colsPerPass) {
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    const int cc = cb + col;
+    if (cc < cpr && rl < rowLanes) {
+      for (long long r = r0 + rl; r < r1; r += rowLanes) {
+        Vec16<T> v; v.load(x + r * cs + (long long)cc * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float f = v.get(e); s[e] += f; q[e] += f * f; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = q[e]; }
+    __syncthreads();
+    if (rl == 0 && cc < cpr) {
+      for (int l = 1; l < rowLanes; ++l)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s[e] += red[0][l * colsPerPass + col][e]; q[e] += red[1][l * colsPerPass + col][e]; }
+      float* o = slab + (size_t)blockIdx.x * 2 * C + (size_t)cc * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { o[e] = s[e]; o[C + e] = q[e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// [rows][width] -> [ROWS_L2][width]; out row j sums rows j, j+32, ... (fixed order)
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ in, int rows, int width,
+                                                          float* __restrict__ out) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int r = blockIdx.x; r < rows; r += ROWS_L2) s += in[(size_t)r * width + c];
+  out[(size_t)blockIdx.x * width + c] = s;
+}
+
+// one thread per channel over a (small) slab [rows][2][C]
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ slab, int rows, int C, float count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         long long* __restrict__ nbt, float momentum, float eps,
+                                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                         float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int r = 0; r < rows; ++r) { s += slab[((size_t)r * 2) * C + c]; q += slab[((size_t)r * 2 + 1) * C + c]; }
+  const float mean = s / count;
+  float var = q / count - mean * mean;
+  if (var < 0.f) var = 0.f;
+  const float invstd = rsqrtf(var + eps);
+  mean_out[c] = mean; invstd_out[c] = invstd;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - mean * g * invstd;
+  if (running_mean) {
+    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+__global__ void __launch_bounds__(64) bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                                            float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = rsqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - rm[c] * g * invstd;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, int x_cs, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res, int r_cs,
+                                                       T* __restrict__ y, int y_cs, long long M, int C, int relu) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = C / VEC;
+  const long long total = M * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long m = i / cpr;
+    const int c = (int)(i - m * cpr) * VEC;
+    Vec16<T> v; v.load(x + m * x_cs + c);
+    Vec16<T> rv; if (res) rv.load(res + m * r_cs + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float f = v.get(e) * scale[c + e] + shift[c + e];
+      if (res) f += rv.get(e);
+      if (relu) f = fmaxf(f, 0.f);
+      o.set(e, f);
+    }
+    o.store(y + m * y_cs + c);
+  }
+}
+
+// dz = dy * (y > 0) (in place over dy when `y` given); slab[block][2][C] = (sum dz, sum dz*xhat)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(T* __restrict__ dy, int dy_cs, const T* __restrict__ y, int y_cs,
+                                                            const T* __restrict__ x, int x_cs, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, long long M, int C,
+                                                            float* __restrict__ slab, int rowsPerBlock) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[2][256][VEC > 4 ? 9 : 5];
+  const int cpr = C / VEC;
+  const int colsPerPass = cpr < 256 ? cpr : 256;
+  const int rowLanes = 256 / colsPerPass;
+  const int tid = threadIdx.x;
+  const int col = tid % colsPerPass, rl = tid / colsPerPass;
+  const long long r0 = (long long)blockIdx.x * rowsPerBlock;
+  long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
+  for (int cb = 0; cb < cpr; cb += colsPerPass) {
+    float s[VEC], q[VEC], mu[VEC], is[VEC];
+    const int cc = cb + col;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+    if (cc < cpr && rl < rowLanes) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { mu[e] = mean[cc * VEC + e]; is[e] = invstd[cc * VEC + e]; }
+      for (long long r = r0 + rl; r < r1; r += rowLanes) {
+        Vec16<T> g; g.load(dy + r * dy_cs + (long long)cc * VEC);
+        Vec16<T> xv; xv.load(x + r * x_cs + (long long)cc * VEC);
+        if (y) {
+          Vec16<T> yv; yv.load(y + r * y_cs + (long long)cc * VEC);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) if (!(yv.get(e) > 0.f)) g.set(e, 0.f);
+          g.store(dy + r * dy_cs + (long long)cc * VEC);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = g.get(e);
+          s[e] += d; q[e] += d * (xv.get(e) - mu[e]) * is[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = q[e]; }
+    __syncthreads();
+    if (rl == 0 && cc < cpr) {
+      for (int l = 1; l < rowLanes; ++l)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s[e] += red[0][l * colsPerPass + col][e]; q[e] += red[1][l * colsPerPass + col][e]; }
+      float* o = slab + (size_t)blockIdx.x * 2 * C + (size_t)cc * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { o[e] = s[e]; o[C + e] = q[e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// slab [rows][2][C] -> dbeta = sum dz, dgamma = sum dz*xhat (written or accumulated into the fp32 grad arena)
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ slab, int rows, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ sums, int accumulate) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int r = 0; r < rows; ++r) { s += slab[((size_t)r * 2) * C + c]; q += slab[((size_t)r * 2 + 1) * C + c]; }
+  sums[c] = s; sums[C + c] = q;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + q : q;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s : s;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz, int dz_cs, const T* __restrict__ x, int x_cs,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                        T* __restrict__ dx, int dx_cs, long long M, int C) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = C / VEC;
+  const long long total = M * cpr;
+  const float invM = 1.0f / (float)M;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long m = i / cpr;
+    const int c = (int)(i - m * cpr) * VEC;
+    Vec16<T> g; g.load(dz + m * dz_cs + c);
+    Vec16<T> xv; xv.load(x + m * x_cs + c);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float is = invstd[c + e];
+      const float xh = (xv.get(e) - mean[c + e]) * is;
+      const float gm = gamma ? gamma[c + e] : 1.f;
+      o.set(e, gm * is * (g.get(e) - sums[c + e] * invM - xh * sums[C + c + e] * invM));
+    }
+    o.store(dx + m * dx_cs + c);
+  }
+}
+
+static int rows_per_block(long long M, int* nblocks) {
+  long long rpb = (M + 1023) / 1024;
+  if (rpb < 8) rpb = 8;
+  *nblocks = (int)((M + rpb - 1) / rpb);
+  return (int)rpb;
+}
+
+// Reduce a [rows][2][C] slab down to <= ROWS_L2 rows if it is tall. Returns the slab to finalize from.
+static const float* shrink_slab(const float* slab, int* rows, int C, float* scratch, hipStream_t s) {
+  if (*rows <= 64) return slab;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ROWS_L2, (2 * C + 255) / 256), dim3(256), 0, s, slab, *rows, 2 * C, scratch);
+  *rows = ROWS_L2;
+  return scratch;
+}
+
+DPA_API int dpa_bn_slab_rows(long long M) { int nb; rows_per_block(M, &nb); return nb; }
+
+// scratch: >= ROWS_L2*2*C floats.  slab: [rows][2][C]
+DPA_API void dpa_bn_stats(const void* x, int dtype, long long M, int C, int cs, float* slab, hipStream_t s) {
+  int nb; const int rpb = rows_per_block(M, &nb);
+  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rpb);
+  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rpb);
+}
+DPA_API void dpa_bn_finalize(const float* slab, int rows, int C, long long count, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
+                             float* mean_out, float* invstd_out, float* scale_out, float* shift_out, float* scratch,
+                             hipStream_t s) {
+  const float* sl = shrink_slab(slab, &rows, C, scratch, s);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, (float)count, gamma, beta,
+                     running_mean, running_var, nbt, momentum, eps, mean_out, invstd_out, scale_out, shift_out);
+}
+DPA_API void dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                float* scale_out, float* shift_out, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, gamma, beta, rm, rv, eps, scale_out, shift_out);
+}
+DPA_API void dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
+                          int y_cs, long long M, int C, int relu, int dtype, hipStream_t s) {
+  const int vec = dtype == 1 ? 8 : 4;
+  const int grid = dpa_grid(M * (C / vec), 256);
+  if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
+                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu);
+  else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
+                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu);
+}
+// slab: >= dpa_bn_slab_rows(M)*2*C floats; scratch >= ROWS_L2*2*C; sums: 2*C floats (kept for bn_bwd_dx)
+DPA_API void dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, const void* x, int x_cs, const float* mean,
+                               const float* invstd, long long M, int C, float* slab, float* scratch, float* dgamma,
+                               float* dbeta, float* sums, int accumulate, int dtype, hipStream_t s) {
+  int nb; const int rpb = rows_per_block(M, &nb);
+  if (dtype == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (bf16_t*)dy, dy_cs, (const bf16_t*)y,
+                                     y_cs, (const bf16_t*)x, x_cs, mean, invstd, M, C, slab, rpb);
+  else            hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, s, (float*)dy, dy_cs, (const float*)y,
+                                     y_cs, (const float*)x, x_cs, mean, invstd, M, C, slab, rpb);
+  int rows = nb;
+  const float* sl = shrink_slab(slab, &rows, C, scratch, s);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate);
+}
+DPA_API void dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* mean, const float* invstd,
+                           const float* gamma, const float* sums, void* dx, int dx_cs, long long M, int C, int dtype,
+                           hipStream_t s) {
+  const int vec = dtype == 1 ? 8 : 4;
+  const int grid = dpa_grid(M * (C / vec), 256);
+  if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
+                                     (const bf16_t*)x, x_cs, mean, invstd, gamma, sums, (bf16_t*)dx, dx_cs, M, C);
+  else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dz, dz_cs,
+                                     (const float*)x, x_cs, mean, invstd, gamma, sums, (float*)dx, dx_cs, M, C);
+}
+
+// Per-channel column sum of a tall activation (conv bias gradients): stats slab -> fixed-order reduce.
+__global__ void __launch_bounds__(64) slab_colsum_finalize_kernel(const float* __restrict__ slab, int rows, int C,
+                                                                  float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += slab[((size_t)r * 2) * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+DPA_API void dpa_colsum_tall(const void* x, int dtype, long long M, int C, int cs, float* slab, float* scratch, float* out,
+                             int accumulate, hipStream_t s) {
+  dpa_bn_stats(x, dtype, M, C, cs, slab, s);
+  int rows = dpa_bn_slab_rows(M);
+  const float* sl = shrink_slab(slab, &rows, C, scratch, s);
+  hipLaunchKernelGGL(slab_colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, out, accumulate);
+}

@@ -1,0 +1,310 @@
+// Pooling for NHWC activations on gfx950 (K9/K10 of SURVEY.md §2.5): MaxPool2d (incl. ceil_mode for SqueezeNet),
+// AvgPool2d (count_include_pad as torch's default) and AdaptiveAvgPool2d, forward and backward.
+// Memory-bound: one thread = one 16-byte channel chunk of one output pixel; backward is gather-style (each
+// input pixel scans the few windows that cover it), so there are no atomics and results are deterministic.
+#include "common.h"
+
+struct PoolP {
+  int N, H, W, C, Ho, Wo;
+  int kh, kw, sh, sw, ph, pw;
+  int x_cs, y_cs;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          unsigned char* __restrict__ idx, PoolP p) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.Ho * p.Wo * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wo = (int)(t % p.Wo); t /= p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    float best[VEC]; unsigned char bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int r = 0; r < p.kh; ++r) {
+      const int hi = ho * p.sh - p.ph + r;
+      if ((unsigned)hi >= (unsigned)p.H) continue;
+      for (int s = 0; s < p.kw; ++s) {
+        const int wi = wo * p.sw - p.pw + s;
+        if ((unsigned)wi >= (unsigned)p.W) continue;
+        Vec16<T> v; v.load(x + ((long long)(n * p.H + hi) * p.W + wi) * p.x_cs + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float f = v.get(e);
+          if (first || f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(r * p.kw + s); }
+        }
+        first = false;
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, best[e]);
+    const long long opix = (long long)(n * p.Ho + ho) * p.Wo + wo;
+    o.store(y + opix * p.y_cs + c);
+    if (idx) {
+      unsigned char* ip = idx + opix * p.C + c;
+      if (VEC == 8) { uint2 pk; unsigned char* b = (unsigned char*)&pk;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) b[e] = bi[e];
+        *reinterpret_cast<uint2*>(ip) = pk;
+      } else { uint32_t pk; unsigned char* b = (unsigned char*)&pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = bi[e];
+        *reinterpret_cast<uint32_t*>(ip) = pk;
+      }
+    }
+  }
+}
+
+// dx[n,hi,wi,c] = sum over windows (ho,wo) covering (hi,wi) with argmax == this tap of dy[n,ho,wo,c]
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                          T* __restrict__ dx, PoolP p, int dy_cs, int dx_cs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.H * p.W * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wi = (int)(t % p.W); t /= p.W;
+    const int hi = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    // ho*sh - ph + r == hi  with 0 <= r < kh
+    int ho_lo = (hi + p.ph - p.kh + p.sh) / p.sh; if (hi + p.ph - p.kh + 1 <= 0) ho_lo = 0;
+    int ho_hi = (hi + p.ph) / p.sh; if (ho_hi >= p.Ho) ho_hi = p.Ho - 1;
+    int wo_lo = (wi + p.pw - p.kw + p.sw) / p.sw; if (wi + p.pw - p.kw + 1 <= 0) wo_lo = 0;
+    int wo_hi = (wi + p.pw) / p.sw; if (wo_hi >= p.Wo) wo_hi = p.Wo - 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const int r = hi + p.ph - ho * p.sh;
+      if (r < 0 || r >= p.kh) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const int s = wi + p.pw - wo * p.sw;
+        if (s < 0 || s >= p.kw) continue;
+        const unsigned char tap = (unsigned char)(r * p.kw + s);
+        const long long opix = (long long)(n * p.Ho + ho) * p.Wo + wo;
+        Vec16<T> g; g.load(dy + opix * dy_cs + c);
+        const unsigned char* ip = idx + opix * p.C + c;
+        unsigned char bi[VEC];
+        if (VEC == 8) { uint2 pk = *reinterpret_cast<const uint2*>(ip); const unsigned char* b = (const unsigned char*)&pk;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) bi[e] = b[e];
+        } else { uint32_t pk = *reinterpret_cast<const uint32_t*>(ip); const unsigned char* b = (const unsigned char*)&pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bi[e] = b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) if (bi[e] == tap) acc[e] += g.get(e);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+    o.store(dx + ((long long)(n * p.H + hi) * p.W + wi) * dx_cs + c);
+  }
+}
+
+// AvgPool2d, divisor = kh*kw (count_include_pad=True, torch default)
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolP p) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.Ho * p.Wo * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float inv = 1.0f / (float)(p.kh * p.kw);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wo = (int)(t % p.Wo); t /= p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int r = 0; r < p.kh; ++r) {
+      const int hi = ho * p.sh - p.ph + r;
+      if ((unsigned)hi >= (unsigned)p.H) continue;
+      for (int s = 0; s < p.kw; ++s) {
+        const int wi = wo * p.sw - p.pw + s;
+        if ((unsigned)wi >= (unsigned)p.W) continue;
+        Vec16<T> v; v.load(x + ((long long)(n * p.H + hi) * p.W + wi) * p.x_cs + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v.get(e);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e] * inv);
+    o.store(y + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.y_cs + c);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, PoolP p,
+                                                          int dy_cs, int dx_cs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.H * p.W * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float inv = 1.0f / (float)(p.kh * p.kw);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wi = (int)(t % p.W); t /= p.W;
+    const int hi = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    int ho_lo = (hi + p.ph - p.kh + p.sh) / p.sh; if (hi + p.ph - p.kh + 1 <= 0) ho_lo = 0;
+    int ho_hi = (hi + p.ph) / p.sh; if (ho_hi >= p.Ho) ho_hi = p.Ho - 1;
+    int wo_lo = (wi + p.pw - p.kw + p.sw) / p.sw; if (wi + p.pw - p.kw + 1 <= 0) wo_lo = 0;
+    int wo_hi = (wi + p.pw) / p.sw; if (wo_hi >= p.Wo) wo_hi = p.Wo - 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const int r = hi + p.ph - ho * p.sh;
+      if (r < 0 || r >= p.kh) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const int s = wi + p.pw - wo * p.sw;
+        if (s < 0 || s >= p.kw) continue;
+        Vec16<T> g; g.load(dy + ((long long)(n * p.Ho + ho) * p.Wo + wo) * dy_cs + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += g.get(e);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e] * inv);
+    o.store(dx + ((long long)(n * p.H + hi) * p.W + wi) * dx_cs + c);
+  }
+}
+
+// AdaptiveAvgPool2d: window i = [floor(i*H/Ho), ceil((i+1)*H/Ho))
+__device__ __forceinline__ int ad_start(int i, int in, int out) { return (i * in) / out; }
+__device__ __forceinline__ int ad_end(int i, int in, int out) { return ((i + 1) * in + out - 1) / out; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) adaptive_avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolP p) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.Ho * p.Wo * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wo = (int)(t % p.Wo); t /= p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    const int h0 = ad_start(ho, p.H, p.Ho), h1 = ad_end(ho, p.H, p.Ho);
+    const int w0 = ad_start(wo, p.W, p.Wo), w1 = ad_end(wo, p.W, p.Wo);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int hi = h0; hi < h1; ++hi)
+      for (int wi = w0; wi < w1; ++wi) {
+        Vec16<T> v; v.load(x + ((long long)(n * p.H + hi) * p.W + wi) * p.x_cs + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v.get(e);
+      }
+    const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e] * inv);
+    o.store(y + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.y_cs + c);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, PoolP p,
+                                                                   int dy_cs, int dx_cs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.H * p.W * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wi = (int)(t % p.W); t /= p.W;
+    const int hi = (int)(t % p.H);
+    const int n = (int)(t / p.H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    // candidate output windows: those whose [start,end) contains hi
+    int ho_lo = (hi * p.Ho) / p.H; if (ho_lo > 0) --ho_lo;
+    int wo_lo = (wi * p.Wo) / p.W; if (wo_lo > 0) --wo_lo;
+    for (int ho = ho_lo; ho < p.Ho; ++ho) {
+      const int h0 = ad_start(ho, p.H, p.Ho), h1 = ad_end(ho, p.H, p.Ho);
+      if (h0 > hi) break;
+      if (hi >= h1) continue;
+      for (int wo = wo_lo; wo < p.Wo; ++wo) {
+        const int w0 = ad_start(wo, p.W, p.Wo), w1 = ad_end(wo, p.W, p.Wo);
+        if (w0 > wi) break;
+        if (wi >= w1) continue;
+        const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+        Vec16<T> g; g.load(dy + ((long long)(n * p.Ho + ho) * p.Wo + wo) * dy_cs + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += g.get(e) * inv;
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+    o.store(dx + ((long long)(n * p.H + hi) * p.W + wi) * dx_cs + c);
+  }
+}
+
+#define POOL_DISPATCH(kern, total, ...)                                                                       \
+  do {                                                                                                        \
+    const int grid = dpa_grid(total, 256);                                                                    \
+    if (dtype == 1) hipLaunchKernelGGL(kern<bf16_t>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);               \
+    else            hipLaunchKernelGGL(kern<float>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
+  } while (0)
+
+DPA_API void dpa_maxpool_fwd(const void* x, void* y, unsigned char* idx, const PoolP* pp, int dtype, hipStream_t s) {
+  PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
+  const long long total = (long long)p.N * p.Ho * p.Wo * (p.C / vec);
+  if (dtype == 1) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, p);
+  else            hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, idx, p);
+}
+DPA_API void dpa_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, const PoolP* pp, int dy_cs, int dx_cs,
+                             int dtype, hipStream_t s) {
+  PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
+  const long long total = (long long)p.N * p.H * p.W * (p.C / vec);
+  if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, p, dy_cs, dx_cs);
+  else            hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, p, dy_cs, dx_cs);
+}
+DPA_API void dpa_avgpool_fwd(const void* x, void* y, const PoolP* pp, int adaptive, int dtype, hipStream_t s) {
+  PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
+  const long long total = (long long)p.N * p.Ho * p.Wo * (p.C / vec);
+  const int grid = dpa_grid(total, 256);
+  if (adaptive) {
+    if (dtype == 1) hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, p);
+    else            hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, p);
+  } else {
+    if (dtype == 1) hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, p);
+    else            hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, p);
+  }
+}
+DPA_API void dpa_avgpool_bwd(const void* dy, void* dx, const PoolP* pp, int dy_cs, int dx_cs, int adaptive, int dtype,
+                             hipStream_t s) {
+  PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
+  const long long total = (long long)p.N * p.H * p.W * (p.C / vec);
+  const int grid = dpa_grid(total, 256);
+  if (adaptive) {
+    if (dtype == 1) hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, p, dy_cs, dx_cs);
+    else            hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (float*)dx, p, dy_cs, dx_cs);
+  } else {
+    if (dtype == 1) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, p, dy_cs, dx_cs);
+    else            hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (float*)dx, p, dy_cs, dx_cs);
+  }
+}
+DPA_API int dpa_pool_params_size() { return (int)sizeof(PoolP); }

@@ -1,0 +1,295 @@
+"""Execution engine: flat parameter arenas + a minimal reverse-mode tape with hand-written backward per layer.
+
+MI355X-first design, not a torch.nn / autograd re-skin:
+  * every parameter lives in ONE fp32 arena (`ParamStore.p`), its gradient at the same offset of a second arena
+    (`.g`) and - in bf16 mode - its compute copy at the same offset of a bf16 shadow arena (`.p16`), so the fused
+    optimizer updates the whole model (or one gradient bucket) with a single launch, the DDP reducer all-reduces
+    contiguous slices with no packing, and zero_grad is one memset;
+  * conv/linear weights are stored in the kernels' layout ([Cout, kh, kw, Cin], channels padded to a multiple of
+    8) and converted to torchvision's OIHW only when a checkpoint is written or read;
+  * activations are NHWC; there is no autograd graph - each layer pushes one closure on the tape.
+PyTorch is used for memory handles (torch.empty on the caching allocator) and nothing else on the hot path.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Callable, List, Optional
+
+import torch
+
+ALIGN = 64          # arena alignment in elements (256 B)
+CPAD = 8            # channel padding granule: one 16-byte chunk of bf16, two of fp32
+
+
+def pad_to(n: int, m: int = CPAD) -> int:
+    return (n + m - 1) // m * m
+
+
+class Act:
+    """An NHWC activation (possibly a channel slice of a wider buffer) plus its gradient slot."""
+    __slots__ = ("data", "grad", "needs_grad", "grad_buf")
+
+    def __init__(self, data: torch.Tensor, needs_grad: bool = False):
+        self.data = data
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+        self.grad_buf: Optional[torch.Tensor] = None   # preassigned gradient storage (slice of a concat grad)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class ParamSpec:
+    __slots__ = ("name", "logical_shape", "storage_shape", "kind", "offset", "numel", "trainable", "index", "meta")
+
+    def __init__(self, name, logical_shape, storage_shape, kind, trainable, meta=None):
+        self.name = name
+        self.logical_shape = tuple(logical_shape)
+        self.storage_shape = tuple(storage_shape)
+        self.kind = kind            # 'conv' (OIHW <-> KRSC), 'vec'
+        self.trainable = trainable
+        self.numel = int(math.prod(storage_shape))
+        self.offset = -1
+        self.index = -1
+        self.meta = meta
+
+
+class ParamStore:
+    """Flat arenas for parameters, gradients and buffers, plus the torchvision-compatible state_dict view."""
+
+    def __init__(self, device, compute_dtype=torch.float32):
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        self.params: List[ParamSpec] = []
+        self.buffers: List[ParamSpec] = []
+        self.entries: List[tuple] = []          # state_dict order: ('param'|'buffer'|'nbt', spec)
+        self._init_values = {}
+        self.p = self.g = self.p16 = self.b = self.nbt = None
+        self.p_size = self.b_size = 0
+        self.n_nbt = 0
+
+    # ---------------------------------------------------------------- registration
+    def add_conv_weight(self, name, cout, cin, kh, kw, init, trainable=True, flat_logical=False):
+        """init: callable(logical_tensor[cout, cin, kh, kw]) filling it in place (torch.nn.init style)."""
+        logical = (cout, cin * kh * kw) if flat_logical else (cout, cin, kh, kw)
+        spec = ParamSpec(name, logical, (pad_to(cout), kh, kw, pad_to(cin)), "conv", trainable,
+                         meta=(cout, cin, kh, kw))
+        t = torch.empty(cout, cin, kh, kw)
+        init(t)
+        self._register(spec, t)
+        return spec
+
+    def add_vec(self, name, n, init, trainable=True):
+        spec = ParamSpec(name, (n,), (pad_to(n),), "vec", trainable, meta=(n,))
+        t = torch.empty(n)
+        init(t)
+        self._register(spec, t)
+        return spec
+
+    def add_buffer(self, name, n, value):
+        spec = ParamSpec(name, (n,), (pad_to(n),), "vec", False, meta=(n,))
+        spec.offset = self.b_size
+        self.b_size += pad_to(spec.numel, ALIGN)
+        spec.index = len(self.buffers)
+        self.buffers.append(spec)
+        self.entries.append(("buffer", spec))
+        self._init_values[("b", spec.index)] = torch.full((n,), float(value))
+        return spec
+
+    def add_nbt(self, name):
+        idx = self.n_nbt
+        self.n_nbt += 1
+        self.entries.append(("nbt", (name, idx)))
+        return idx
+
+    def _register(self, spec, value):
+        spec.offset = self.p_size
+        self.p_size += pad_to(spec.numel, ALIGN)
+        spec.index = len(self.params)
+        self.params.append(spec)
+        self.entries.append(("param", spec))
+        self._init_values[("p", spec.index)] = value
+
+    # ---------------------------------------------------------------- materialisation
+    def finalize(self):
+        dev = self.device
+        self.p = torch.zeros(max(self.p_size, ALIGN), device=dev)
+        self.g = torch.zeros_like(self.p)
+        self.b = torch.zeros(max(self.b_size, ALIGN), device=dev)
+        self.nbt = torch.zeros(max(self.n_nbt, 1), dtype=torch.int64, device=dev)
+        for spec in self.params:
+            self.set_logical(spec, self._init_values.pop(("p", spec.index)))
+        for spec in self.buffers:
+            self.bview(spec)[: spec.meta[0]].copy_(self._init_values.pop(("b", spec.index)))
+        if self.compute_dtype == torch.bfloat16:
+            self.p16 = torch.zeros(self.p.numel(), device=dev, dtype=torch.bfloat16)
+            self.refresh_compute_copy()
+        return self
+
+    def refresh_compute_copy(self):
+        if self.p16 is not None:
+            from .. import ops
+            ops.cast(self.p, self.p16)
+
+    def view(self, spec):      # fp32 master, storage layout
+        return self.p[spec.offset: spec.offset + spec.numel].view(spec.storage_shape)
+
+    def gview(self, spec):
+        return self.g[spec.offset: spec.offset + spec.numel].view(spec.storage_shape)
+
+    def cview(self, spec):     # compute-dtype copy the kernels read
+        src = self.p16 if self.p16 is not None else self.p
+        return src[spec.offset: spec.offset + spec.numel].view(spec.storage_shape)
+
+    def bview(self, spec):
+        return self.b[spec.offset: spec.offset + spec.numel]
+
+    # ---------------------------------------------------------------- logical (torchvision) <-> storage
+    @staticmethod
+    def storage_to_logical(spec, st):
+        if spec.kind == "conv":
+            cout, cin, kh, kw = spec.meta
+            return st[:cout, :, :, :cin].permute(0, 3, 1, 2).contiguous().view(spec.logical_shape)
+        return st[: spec.meta[0]].clone()
+
+    @staticmethod
+    def logical_to_storage(spec, logical, out):
+        out.zero_()
+        if spec.kind == "conv":
+            cout, cin, kh, kw = spec.meta
+            out[:cout, :, :, :cin].copy_(logical.reshape(cout, cin, kh, kw).permute(0, 2, 3, 1))
+        else:
+            out[: spec.meta[0]].copy_(logical.reshape(-1))
+        return out
+
+    def get_logical(self, spec):
+        return self.storage_to_logical(spec, self.view(spec))
+
+    def set_logical(self, spec, value):
+        self.logical_to_storage(spec, value.to(self.device, torch.float32), self.view(spec))
+
+    def trainable_ranges(self):
+        """Maximal contiguous arena ranges [lo, hi) covering trainable parameters, in arena order."""
+        ranges = []
+        for spec in self.params:
+            if not spec.trainable:
+                continue
+            lo, hi = spec.offset, spec.offset + pad_to(spec.numel, ALIGN)
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1][1] = hi
+            else:
+                ranges.append([lo, hi])
+        return [tuple(r) for r in ranges]
+
+    # ---------------------------------------------------------------- state_dict (torchvision names)
+    def state_dict(self, prefix=""):
+        sd = OrderedDict()
+        for kind, item in self.entries:
+            if kind == "param":
+                sd[prefix + item.name] = self.get_logical(item)
+            elif kind == "buffer":
+                sd[prefix + item.name] = self.bview(item)[: item.meta[0]].clone()
+            else:
+                name, idx = item
+                sd[prefix + name] = self.nbt[idx].clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        """Accepts keys with or without the DDP 'module.' prefix (Q16 of SURVEY.md §2.8)."""
+        clean = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        expected = []
+        for kind, item in self.entries:
+            name = item.name if kind != "nbt" else item[0]
+            expected.append(name)
+            if name not in clean:
+                if strict:
+                    raise KeyError(f"missing key in state_dict: {name}")
+                continue
+            v = clean[name]
+            if kind == "param":
+                if tuple(v.shape) != item.logical_shape:
+                    raise ValueError(f"shape mismatch for {name}: {tuple(v.shape)} vs {item.logical_shape}")
+                self.set_logical(item, v)
+            elif kind == "buffer":
+                self.bview(item)[: item.meta[0]].copy_(v.to(self.device, torch.float32))
+            else:
+                self.nbt[item[1]] = int(v)
+        if strict:
+            extra = set(clean) - set(expected)
+            if extra:
+                raise KeyError(f"unexpected keys in state_dict: {sorted(extra)[:5]}")
+        self.refresh_compute_copy()
+
+    def num_parameters(self):
+        return sum(int(math.prod(s.logical_shape)) for s in self.params)
+
+
+class Tape:
+    """Reverse-mode tape: layers push closures during forward; backward() pops them in reverse order."""
+
+    def __init__(self):
+        self.fns: List[Callable[[], None]] = []
+        self.param_ready_hook: Optional[Callable[[ParamSpec], None]] = None
+
+    def push(self, fn):
+        self.fns.append(fn)
+
+    def backward(self):
+        while self.fns:
+            self.fns.pop()()
+
+    def ready(self, spec):
+        """Called by a layer when the gradient of `spec` is final for this step (feeds the DDP reducer)."""
+        if self.param_ready_hook is not None:
+            self.param_ready_hook(spec)
+
+
+class Context:
+    """Per-forward state: tape, mode flags, shared workspaces."""
+
+    def __init__(self, store: ParamStore, training: bool, tape: Optional[Tape] = None, rng=None):
+        self.store = store
+        self.training = training
+        self.tape = tape
+        self.rng = rng                       # uint64[2] device tensor (seed, step) for dropout
+        self.device = store.device
+        self.dtype = store.compute_dtype
+        self.cuda = store.device.type == "cuda"
+
+    @property
+    def grad_enabled(self):
+        return self.tape is not None
+
+    def empty(self, shape):
+        return torch.empty(shape, device=self.device, dtype=self.dtype)
+
+    def zeros(self, shape):
+        return torch.zeros(shape, device=self.device, dtype=self.dtype)
+
+
+_workspaces = {}
+
+
+def workspace(device, n, tag, dtype=torch.float32):
+    """Persistent scratch (stream-ordered reuse; never freed so captured graphs keep valid pointers)."""
+    key = (str(device), tag, dtype)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(int(n), 1 << 14), device=device, dtype=dtype)
+        _workspaces[key] = buf
+    return buf
+
+
+def accumulate_grad(act: Act, g: torch.Tensor):
+    """act.grad += g (first contribution is adopted without a copy)."""
+    from .. import ops
+    if act.grad is None:
+        if act.grad_buf is not None and act.grad_buf.data_ptr() != g.data_ptr():
+            ops.copy(g, act.grad_buf)
+            act.grad = act.grad_buf
+        else:
+            act.grad = g
+    else:
+        ops.add(act.grad, g, act.grad)

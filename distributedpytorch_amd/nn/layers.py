@@ -1,0 +1,379 @@
+"""Layers with hand-written backward passes over the ops in distributedpytorch_amd.ops (HIP on GPU).
+
+Every layer follows the same protocol: `layer(ctx, x: Act, ...) -> Act`; when `ctx.tape` is set and the output
+needs a gradient, the layer pushes ONE closure that consumes `y.grad`, writes parameter gradients straight into the
+gradient arena (no zero_grad needed: gradients are written, not accumulated), announces them to the DDP reducer via
+`tape.ready(spec)` and accumulates the input gradient.
+Names of parameters follow torchvision so checkpoints interoperate with the reference (/root/reference/utils.py:112-136).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import ops
+from .engine import Act, Context, ParamStore, accumulate_grad, pad_to, workspace
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+# ------------------------------------------------------------------------------------------------ init helpers
+def kaiming_normal_fan_out(t):
+    torch.nn.init.kaiming_normal_(t, mode="fan_out", nonlinearity="relu")
+
+
+def kaiming_uniform_default(t):          # nn.Conv2d / nn.Linear default
+    torch.nn.init.kaiming_uniform_(t.view(t.shape[0], -1), a=math.sqrt(5))
+
+
+def bias_default(fan_in):
+    bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+
+    def init(t):
+        torch.nn.init.uniform_(t, -bound, bound)
+    return init
+
+
+def normal_(std):
+    def init(t):
+        torch.nn.init.normal_(t, 0.0, std)
+    return init
+
+
+def trunc_normal_(std):
+    def init(t):
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std)
+    return init
+
+
+def zeros_(t):
+    t.zero_()
+
+
+def ones_(t):
+    t.fill_(1.0)
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+class Conv2d:
+    """Convolution (also Linear: a kh x kw 'valid' conv over the whole map, or 1x1 on [N,1,1,C])."""
+
+    def __init__(self, store: ParamStore, name, cin, cout, ksize, stride=1, padding=0, bias=True,
+                 w_init=kaiming_uniform_default, b_init=None, trainable=True, linear=False):
+        self.store = store
+        self.cin, self.cout = cin, cout
+        self.ksize, self.stride, self.padding = _pair(ksize), _pair(stride), _pair(padding)
+        kh, kw = self.ksize
+        self.w = store.add_conv_weight(f"{name}.weight", cout, cin, kh, kw, w_init, trainable, flat_logical=linear)
+        self.b = None
+        if bias:
+            self.b = store.add_vec(f"{name}.bias", cout, b_init or bias_default(cin * kh * kw), trainable)
+        self.trainable = trainable
+        self._wt = None
+
+    def out_hw(self, h, w):
+        return (ops.out_size(h, self.ksize[0], self.stride[0], self.padding[0]),
+                ops.out_size(w, self.ksize[1], self.stride[1], self.padding[1]))
+
+    def forward_raw(self, ctx: Context, x: torch.Tensor, out=None, relu=False, stats=None):
+        n, h, w, _ = x.shape
+        ho, wo = self.out_hw(h, w)
+        if out is None:
+            out = ctx.empty((n, ho, wo, pad_to(self.cout)))
+        bias = self.store.view(self.b) if self.b is not None else None
+        ops.conv_fprop(x, self.store.cview(self.w), out, self.stride, self.padding, bias=bias, relu=relu, stats=stats)
+        return out
+
+    def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor):
+        """dy is the gradient w.r.t. the raw conv output (pre-activation).  Writes dW/db, accumulates dx."""
+        st = self.store
+        if self.trainable:
+            if self.b is not None:
+                ops.colsum(dy, st.gview(self.b))
+                ctx.tape.ready(self.b)
+            rsc = self.ksize[0] * self.ksize[1] * x.data.shape[3]
+            ws = workspace(ctx.device, ops.wgrad_workspace_numel(pad_to(self.cout), rsc, ctx.cuda), "wgrad") if ctx.cuda else None
+            ops.conv_wgrad(dy, x.data, st.gview(self.w), self.ksize, self.stride, self.padding, workspace=ws)
+            ctx.tape.ready(self.w)
+        if x.needs_grad:
+            w = st.cview(self.w)
+            if self._wt is None:
+                k, r, s, c = w.shape
+                self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
+            ops.transpose_krsc(w, self._wt)
+            if x.grad is None:
+                dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
+                ops.conv_dgrad(dy, self._wt, dx, self.stride, self.padding)
+                x.grad = dx
+            else:
+                ops.conv_dgrad(dy, self._wt, x.grad, self.stride, self.padding, addend=x.grad)
+
+    def __call__(self, ctx: Context, x: Act, relu=False, out=None) -> Act:
+        y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
+        if ctx.grad_enabled and y.needs_grad:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                if relu:
+                    ops.relu_bwd(dy, y.data)
+                self.backward_raw(ctx, x, dy)
+            ctx.tape.push(bw)
+        return y
+
+
+class BatchNorm2d:
+    def __init__(self, store: ParamStore, name, c, eps=1e-5, momentum=0.1, trainable=True):
+        self.store, self.c, self.eps, self.momentum = store, c, eps, momentum
+        self.gamma = store.add_vec(f"{name}.weight", c, ones_, trainable)
+        self.beta = store.add_vec(f"{name}.bias", c, zeros_, trainable)
+        self.rm = store.add_buffer(f"{name}.running_mean", c, 0.0)
+        self.rv = store.add_buffer(f"{name}.running_var", c, 1.0)
+        self.nbt = store.add_nbt(f"{name}.num_batches_tracked")
+        self.trainable = trainable
+        self._aux = None
+
+    def aux(self, device):
+        """Persistent per-layer fp32 vectors: mean, invstd, scale, shift, sums[2]."""
+        if self._aux is None:
+            cp = pad_to(self.c)
+            self._aux = torch.zeros(6, cp, device=device)
+        return self._aux
+
+    def coeffs(self, ctx: Context, slab, count):
+        """Finalize batch statistics (train) or fold running statistics (eval) into (scale, shift)."""
+        st = self.store
+        a = self.aux(ctx.device)
+        if ctx.training:
+            ops.bn_finalize(slab, count, st.view(self.gamma), st.view(self.beta), st.bview(self.rm), st.bview(self.rv),
+                            st.nbt[self.nbt: self.nbt + 1], self.momentum, self.eps, a[0], a[1], a[2], a[3])
+        else:
+            ops.bn_eval_coeffs(st.view(self.gamma), st.view(self.beta), st.bview(self.rm), st.bview(self.rv), self.eps,
+                               a[2], a[3])
+        return a
+
+    def backward(self, ctx: Context, dy, y_for_mask, z, dx_out):
+        """dz = dy*(y>0) in place; dgamma/dbeta -> arena; returns dx (written into dx_out)."""
+        st = self.store
+        a = self.aux(ctx.device)
+        dg = st.gview(self.gamma) if self.trainable else None
+        db = st.gview(self.beta) if self.trainable else None
+        ops.bn_bwd_reduce(dy, y_for_mask, z, a[0], a[1], dg, db, a[4:6])
+        if self.trainable:
+            ctx.tape.ready(self.gamma)
+            ctx.tape.ready(self.beta)
+        ops.bn_bwd_dx(dy, z, a[0], a[1], st.view(self.gamma), a[4:6], dx_out)
+        return dx_out
+
+
+def _stats_slab(ctx, m, c, conv_fused):
+    rows = ops.stats_rows(m, c, ctx.cuda) if conv_fused else ops.bn_slab_rows(m, ctx.cuda)
+    return workspace(ctx.device, rows * 2 * c, "bn_slab")[: rows * 2 * c].view(rows, 2, c)
+
+
+class ConvBNAct:
+    """conv -> BatchNorm -> (+ residual) -> (ReLU).  BN batch statistics come out of the conv epilogue."""
+
+    def __init__(self, conv: Conv2d, bn: BatchNorm2d):
+        self.conv, self.bn = conv, bn
+
+    def __call__(self, ctx: Context, x: Act, relu=True, residual: Act = None, out=None) -> Act:
+        conv, bn = self.conv, self.bn
+        n, h, w, _ = x.data.shape
+        ho, wo = conv.out_hw(h, w)
+        m, cp = n * ho * wo, pad_to(conv.cout)
+        slab = _stats_slab(ctx, m, cp, True) if ctx.training else None
+        z = conv.forward_raw(ctx, x.data, stats=slab)
+        a = bn.coeffs(ctx, slab, m)
+        if out is None:
+            out = ctx.empty((n, ho, wo, cp))
+        ops.bn_apply(z, a[2], a[3], out, residual=None if residual is None else residual.data, relu=relu)
+        needs = x.needs_grad or conv.trainable or bn.trainable or (residual is not None and residual.needs_grad)
+        y = Act(out, needs)
+        if ctx.grad_enabled and needs:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                dz = bn.backward(ctx, dy, y.data if relu else None, z, z)   # dx overwrites z (dead after this)
+                if residual is not None and residual.needs_grad:
+                    accumulate_grad(residual, dy)                            # dy now holds dy*(y>0)
+                conv.backward_raw(ctx, x, dz)
+            ctx.tape.push(bw)
+        return y
+
+
+class BNAct:
+    """Stand-alone BatchNorm (+ReLU) on an arbitrary (possibly channel-sliced) activation: DenseNet pre-activation."""
+
+    def __init__(self, bn: BatchNorm2d):
+        self.bn = bn
+
+    def __call__(self, ctx: Context, x: Act, relu=True, out=None) -> Act:
+        bn = self.bn
+        n, h, w, c = x.data.shape
+        m = n * h * w
+        slab = None
+        if ctx.training:
+            slab = _stats_slab(ctx, m, c, False)
+            ops.bn_stats(x.data, slab)
+        a = bn.coeffs(ctx, slab, m)
+        if out is None:
+            out = ctx.empty((n, h, w, c))
+        ops.bn_apply(x.data, a[2], a[3], out, relu=relu)
+        needs = x.needs_grad or bn.trainable
+        y = Act(out, needs)
+        if ctx.grad_enabled and needs:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                dx = ctx.empty((n, h, w, c))
+                bn.backward(ctx, dy, y.data if relu else None, x.data, dx)
+                if x.needs_grad:
+                    accumulate_grad(x, dx)
+            ctx.tape.push(bw)
+        return y
+
+
+class Linear(Conv2d):
+    """nn.Linear as a convolution: [N,1,1,in] x 1x1, or (after a spatial map) [N,H,W,C] x (H x W) 'valid'."""
+
+    def __init__(self, store, name, in_features, out_features, spatial=None, **kw):
+        if spatial is None:
+            super().__init__(store, name, in_features, out_features, 1, linear=True, **kw)
+        else:
+            c, h, w = spatial
+            assert c * h * w == in_features
+            super().__init__(store, name, c, out_features, (h, w), linear=True, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ pooling etc.
+class MaxPool2d:
+    def __init__(self, ksize, stride, padding=0, ceil_mode=False):
+        self.ksize, self.stride, self.padding, self.ceil_mode = _pair(ksize), _pair(stride), _pair(padding), ceil_mode
+
+    def __call__(self, ctx: Context, x: Act, out=None) -> Act:
+        n, h, w, c = x.data.shape
+        ho = ops.pool_out_size(h, self.ksize[0], self.stride[0], self.padding[0], self.ceil_mode)
+        wo = ops.pool_out_size(w, self.ksize[1], self.stride[1], self.padding[1], self.ceil_mode)
+        if out is None:
+            out = ctx.empty((n, ho, wo, c))
+        track = ctx.grad_enabled and x.needs_grad
+        idx = torch.empty((n, ho, wo, c), device=ctx.device, dtype=torch.uint8) if track else None
+        ops.maxpool_fwd(x.data, out, idx, self.ksize, self.stride, self.padding)
+        y = Act(out, x.needs_grad)
+        if track:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                dx = ctx.empty((n, h, w, c))
+                ops.maxpool_bwd(dy, idx, dx, self.ksize, self.stride, self.padding)
+                accumulate_grad(x, dx)
+            ctx.tape.push(bw)
+        return y
+
+
+class AvgPool2d:
+    """AvgPool2d(k, s, p) (count_include_pad=True) or AdaptiveAvgPool2d(output_size) when `adaptive` is given."""
+
+    def __init__(self, ksize=None, stride=None, padding=0, adaptive=None):
+        self.adaptive = _pair(adaptive) if adaptive is not None else None
+        self.ksize = _pair(ksize) if ksize is not None else None
+        self.stride = _pair(stride if stride is not None else ksize) if ksize is not None else None
+        self.padding = _pair(padding)
+
+    def __call__(self, ctx: Context, x: Act, out=None) -> Act:
+        n, h, w, c = x.data.shape
+        if self.adaptive is not None:
+            ho, wo = self.adaptive
+        else:
+            ho = ops.pool_out_size(h, self.ksize[0], self.stride[0], self.padding[0])
+            wo = ops.pool_out_size(w, self.ksize[1], self.stride[1], self.padding[1])
+        if out is None:
+            out = ctx.empty((n, ho, wo, c))
+        ad = self.adaptive is not None
+        ops.avgpool_fwd(x.data, out, self.ksize, self.stride, self.padding, adaptive=ad)
+        y = Act(out, x.needs_grad)
+        if ctx.grad_enabled and x.needs_grad:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                dx = ctx.empty((n, h, w, c))
+                ops.avgpool_bwd(dy, dx, self.ksize, self.stride, self.padding, adaptive=ad)
+                accumulate_grad(x, dx)
+            ctx.tape.push(bw)
+        return y
+
+
+class ReLU:
+    def __call__(self, ctx: Context, x: Act, out=None) -> Act:
+        if out is None:
+            out = ctx.empty(tuple(x.data.shape))
+        ops.relu_fwd(x.data, out)
+        y = Act(out, x.needs_grad)
+        if ctx.grad_enabled and x.needs_grad:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                ops.relu_bwd(dy, y.data)
+                accumulate_grad(x, dy)
+            ctx.tape.push(bw)
+        return y
+
+
+_dropout_ids = [0]
+
+
+class Dropout:
+    """Inverted dropout with a Philox counter mask keyed by (seed, step, layer id); the backward pass regenerates
+    the mask instead of storing it (K13 of SURVEY.md §2.5)."""
+
+    def __init__(self, p=0.5):
+        self.p = p
+        _dropout_ids[0] += 1
+        self.layer_id = _dropout_ids[0]
+
+    def __call__(self, ctx: Context, x: Act) -> Act:
+        if not ctx.training or self.p == 0.0:
+            return x
+        out = ctx.empty(tuple(x.data.shape))
+        ops.dropout(x.data, out, self.p, ctx.rng, self.layer_id)
+        y = Act(out, x.needs_grad)
+        if ctx.grad_enabled and x.needs_grad:
+            def bw():
+                dy = y.grad
+                y.grad = None
+                ops.dropout(dy, dy, self.p, ctx.rng, self.layer_id)     # same mask, same scale
+                accumulate_grad(x, dy)
+            ctx.tape.push(bw)
+        return y
+
+
+def concat_buffer(ctx: Context, n, h, w, channels):
+    """Allocate one wide NHWC buffer; branch i writes its output straight into slices[i] (zero-copy concat)."""
+    total = sum(channels)
+    buf = ctx.empty((n, h, w, total))
+    slices, off = [], 0
+    for c in channels:
+        slices.append(buf[..., off: off + c])
+        off += c
+    return buf, slices
+
+
+def concat(ctx: Context, buf: torch.Tensor, branches) -> Act:
+    """branches: Acts whose .data are consecutive channel slices of `buf`."""
+    needs = any(b.needs_grad for b in branches)
+    y = Act(buf, needs)
+    if ctx.grad_enabled and needs:
+        def bw():
+            g = y.grad
+            y.grad = None
+            off = 0
+            for b in branches:
+                c = b.data.shape[3]
+                if b.needs_grad:
+                    accumulate_grad(b, g[..., off: off + c])
+                off += c
+        ctx.tape.push(bw)
+    return y

@@ -1,0 +1,57 @@
+"""Op dispatch: tensors on the GPU run the hand-written gfx950 kernels (hip_ops); tensors on the CPU run the
+plain-PyTorch reference (ref_ops, also the test oracle).  The first positional argument decides."""
+from __future__ import annotations
+
+from . import ref_ops
+
+_hip_ops = None
+
+
+def _hip():
+    global _hip_ops
+    if _hip_ops is None:
+        from . import hip_ops as _h   # raises loudly if the native library is missing
+        _h._lib()
+        _hip_ops = _h
+    return _hip_ops
+
+
+_TENSOR_OPS = [
+    "conv_fprop", "conv_dgrad", "conv_wgrad", "transpose_krsc",
+    "bn_stats", "bn_finalize", "bn_eval_coeffs", "bn_apply", "bn_bwd_reduce", "bn_bwd_dx",
+    "relu_fwd", "relu_bwd", "add", "copy", "dropout", "rng_advance", "colsum",
+    "maxpool_fwd", "maxpool_bwd", "avgpool_fwd", "avgpool_bwd",
+    "ce_loss", "adam_step", "sgd_step", "advance_step", "cast", "augment_mnist",
+]
+
+
+def _make(name):
+    ref_fn = getattr(ref_ops, name)
+
+    def op(t, *args, **kwargs):
+        if t.is_cuda:
+            return getattr(_hip(), name)(t, *args, **kwargs)
+        return ref_fn(t, *args, **kwargs)
+
+    op.__name__ = name
+    op.__doc__ = ref_fn.__doc__
+    return op
+
+
+for _n in _TENSOR_OPS:
+    globals()[_n] = _make(_n)
+
+out_size = ref_ops.out_size
+pool_out_size = ref_ops.pool_out_size
+
+
+def stats_rows(m, cout, cuda):
+    return _hip().stats_rows(m, cout) if cuda else 1
+
+
+def bn_slab_rows(m, cuda):
+    return _hip().bn_slab_rows(m) if cuda else 1
+
+
+def wgrad_workspace_numel(cout, rsc, cuda):
+    return _hip().wgrad_workspace_numel(cout, rsc) if cuda else 1

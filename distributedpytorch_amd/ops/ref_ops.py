@@ -1,0 +1,393 @@
+"""Plain-PyTorch implementation of every op with the SAME signatures as hip_ops.
+
+Two roles: (1) the CPU execution path (config 1 of BASELINE.json: gloo, world_size=2, no GPU) and (2) the
+numerics oracle the HIP kernels are tested against.  Everything is NHWC; tensors may be channel slices.
+Nothing here runs when tensors live on the GPU - the dispatcher in ops/__init__.py sends those to hip_ops.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1)
+
+
+def out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+# ----------------------------------------------------------------------------------------- convolution
+def stats_rows(m, cout):
+    return 1
+
+
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None):
+    out = F.conv2d(_nchw(x).float(), _nchw(w).float(), None if bias is None else bias.float()[: w.shape[0]],
+                   stride=stride, padding=pad)
+    out = _nhwc(out)
+    stored = out.to(y.dtype)
+    if stats is not None:
+        sf = stored.float().reshape(-1, stored.shape[-1])
+        stats.zero_()
+        stats[0, 0] = sf.sum(0)
+        stats[0, 1] = (sf * sf).sum(0)
+    if addend is not None:
+        out = out + addend.float()
+    if relu:
+        out = out.clamp_min(0)
+    y.copy_(out.to(y.dtype))
+    return y
+
+
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None):
+    # wt: [Cin, kh, kw, Cout]  -> torch weight [Cout, Cin, kh, kw]
+    w = wt.permute(3, 0, 1, 2).float()
+    n, h, wd, c = dx.shape
+    g = torch.nn.grad.conv2d_input((n, c, h, wd), w, _nchw(dy).float(), stride=stride, padding=pad)
+    g = _nhwc(g)
+    if addend is not None:
+        g = g + addend.float()
+    dx.copy_(g.to(dx.dtype))
+    return dx
+
+
+def wgrad_workspace_numel(cout, rsc):
+    return 1
+
+
+def conv_wgrad(dy, x, dw, ksize, stride, pad, workspace=None, accumulate=False):
+    k, c = dy.shape[3], x.shape[3]
+    g = torch.nn.grad.conv2d_weight(_nchw(x).float(), (k, c, ksize[0], ksize[1]), _nchw(dy).float(), stride=stride,
+                                    padding=pad)
+    g = g.permute(0, 2, 3, 1).reshape(dw.shape)
+    if accumulate:
+        dw.add_(g)
+    else:
+        dw.copy_(g)
+    return dw
+
+
+def transpose_krsc(w, wt):
+    wt.copy_(w.permute(3, 1, 2, 0))
+    return wt
+
+
+# ----------------------------------------------------------------------------------------- batch norm
+def bn_slab_rows(m):
+    return 1
+
+
+def bn_stats(x, slab):
+    xf = x.float().reshape(-1, x.shape[-1])
+    slab.zero_()
+    slab[0, 0] = xf.sum(0)
+    slab[0, 1] = (xf * xf).sum(0)
+    return slab
+
+
+def bn_finalize(slab, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift,
+                scratch=None):
+    s = slab.sum(0)
+    m = s[0] / count
+    var = (s[1] / count - m * m).clamp_min(0)
+    inv = torch.rsqrt(var + eps)
+    mean.copy_(m)
+    invstd.copy_(inv)
+    g = gamma if gamma is not None else torch.ones_like(m)
+    b = beta if beta is not None else torch.zeros_like(m)
+    scale.copy_(g * inv)
+    shift.copy_(b - m * g * inv)
+    if running_mean is not None:
+        unbiased = var * count / (count - 1) if count > 1 else var
+        running_mean.mul_(1 - momentum).add_(momentum * m)
+        running_var.mul_(1 - momentum).add_(momentum * unbiased)
+    if nbt is not None:
+        nbt.add_(1)
+
+
+def bn_eval_coeffs(gamma, beta, rm, rv, eps, scale, shift):
+    inv = torch.rsqrt(rv + eps)
+    g = gamma if gamma is not None else torch.ones_like(rm)
+    b = beta if beta is not None else torch.zeros_like(rm)
+    scale.copy_(g * inv)
+    shift.copy_(b - rm * g * inv)
+
+
+def bn_apply(x, scale, shift, y, residual=None, relu=False):
+    out = x.float() * scale + shift
+    if residual is not None:
+        out = out + residual.float()
+    if relu:
+        out = out.clamp_min(0)
+    y.copy_(out.to(y.dtype))
+    return y
+
+
+def bn_bwd_reduce(dy, y, x, mean, invstd, dgamma, dbeta, sums, slab=None, scratch=None, accumulate=False):
+    """Masks dy in place by (y > 0) when y is given; writes sums[0]=sum dz, sums[1]=sum dz*xhat; dgamma/dbeta."""
+    if y is not None:
+        dy.mul_((y > 0).to(dy.dtype))
+    dz = dy.float().reshape(-1, dy.shape[-1])
+    xh = (x.float().reshape(-1, x.shape[-1]) - mean) * invstd
+    s = dz.sum(0)
+    q = (dz * xh).sum(0)
+    sums[0].copy_(s)
+    sums[1].copy_(q)
+    if dgamma is not None:
+        if accumulate:
+            dgamma.add_(q)
+        else:
+            dgamma.copy_(q)
+    if dbeta is not None:
+        if accumulate:
+            dbeta.add_(s)
+        else:
+            dbeta.copy_(s)
+
+
+def bn_bwd_dx(dz, x, mean, invstd, gamma, sums, dx):
+    m = dz.numel() // dz.shape[-1]
+    xh = (x.float() - mean) * invstd
+    g = gamma if gamma is not None else 1.0
+    out = g * invstd * (dz.float() - sums[0] / m - xh * sums[1] / m)
+    dx.copy_(out.to(dx.dtype))
+    return dx
+
+
+# ----------------------------------------------------------------------------------------- elementwise
+def relu_fwd(x, y):
+    y.copy_(x.clamp_min(0))
+    return y
+
+
+def relu_bwd(dy, y):
+    dy.mul_((y > 0).to(dy.dtype))
+    return dy
+
+
+def add(a, b, out):
+    out.copy_((a.float() + b.float()).to(out.dtype))
+    return out
+
+
+def copy(a, out):
+    out.copy_(a)
+    return out
+
+
+def _philox_mask(shape, p, rng, layer_id, device):
+    # CPU masks come from a torch generator keyed like the device Philox stream (seed, step, layer): deterministic
+    # and identical between forward and backward, not bit-identical to the device stream.
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(rng[0]) * 1000003 + int(rng[1]) * 8191 + int(layer_id)) % (2 ** 63 - 1))
+    return (torch.rand(shape, generator=g) >= p).to(device)
+
+
+def dropout(x, y, p, rng, layer_id):
+    keep = _philox_mask(tuple(x.shape), p, rng, layer_id, x.device)
+    y.copy_((x.float() * keep / (1.0 - p)).to(y.dtype))
+    return y
+
+
+def rng_advance(rng):
+    rng[1] += 1
+
+
+def colsum(x, out, accumulate=False):
+    s = x.float().reshape(-1, x.shape[-1]).sum(0)
+    if accumulate:
+        out.add_(s)
+    else:
+        out.copy_(s)
+    return out
+
+
+# ----------------------------------------------------------------------------------------- pooling
+def pool_out_size(h, k, s, p, ceil_mode=False):
+    if ceil_mode:
+        o = -(-(h + 2 * p - k) // s) + 1
+        if (o - 1) * s >= h + p:
+            o -= 1
+        return o
+    return (h + 2 * p - k) // s + 1
+
+
+def maxpool_fwd(x, y, idx, ksize, stride, pad):
+    n, h, w, c = x.shape
+    ho, wo = y.shape[1], y.shape[2]
+    # emulate ceil_mode by padding -inf on the bottom/right as needed
+    need_h = (ho - 1) * stride[0] + ksize[0] - (h + 2 * pad[0])
+    need_w = (wo - 1) * stride[1] + ksize[1] - (w + 2 * pad[1])
+    xp = F.pad(_nchw(x).float(), (pad[1], pad[1] + max(need_w, 0), pad[0], pad[0] + max(need_h, 0)), value=float("-inf"))
+    cols = F.unfold(xp, ksize, stride=stride).reshape(n, c, ksize[0] * ksize[1], ho, wo)
+    val, arg = cols.max(dim=2)
+    y.copy_(_nhwc(val).to(y.dtype))
+    if idx is not None:
+        idx.copy_(_nhwc(arg).to(torch.uint8))
+    return y
+
+
+def maxpool_bwd(dy, idx, dx, ksize, stride, pad):
+    n, h, w, c = dx.shape
+    ho, wo = dy.shape[1], dy.shape[2]
+    need_h = max((ho - 1) * stride[0] + ksize[0] - (h + 2 * pad[0]), 0)
+    need_w = max((wo - 1) * stride[1] + ksize[1] - (w + 2 * pad[1]), 0)
+    kk = ksize[0] * ksize[1]
+    onehot = F.one_hot(_nchw(idx).long(), kk).permute(0, 1, 4, 2, 3).float()      # n c kk ho wo
+    cols = (onehot * _nchw(dy).float().unsqueeze(2)).reshape(n, c * kk, ho * wo)
+    g = F.fold(cols, (h + 2 * pad[0] + need_h, w + 2 * pad[1] + need_w), ksize, stride=stride)
+    g = g[:, :, pad[0]:pad[0] + h, pad[1]:pad[1] + w]
+    dx.copy_(_nhwc(g).to(dx.dtype))
+    return dx
+
+
+def avgpool_fwd(x, y, ksize, stride, pad, adaptive=False):
+    if adaptive:
+        out = F.adaptive_avg_pool2d(_nchw(x).float(), (y.shape[1], y.shape[2]))
+    else:
+        out = F.avg_pool2d(_nchw(x).float(), ksize, stride=stride, padding=pad)
+    y.copy_(_nhwc(out).to(y.dtype))
+    return y
+
+
+def avgpool_bwd(dy, dx, ksize, stride, pad, adaptive=False):
+    xin = torch.zeros(dx.shape[0], dx.shape[3], dx.shape[1], dx.shape[2], requires_grad=True)
+    if adaptive:
+        out = F.adaptive_avg_pool2d(xin, (dy.shape[1], dy.shape[2]))
+    else:
+        out = F.avg_pool2d(xin, ksize, stride=stride, padding=pad)
+    (g,) = torch.autograd.grad(out, xin, _nchw(dy).float())
+    dx.copy_(_nhwc(g).to(dx.dtype))
+    return dx
+
+
+# ----------------------------------------------------------------------------------------- loss
+def ce_loss(logits, labels, num_classes, out, accum=None, dlogits=None, class_w=None, mode=0, gamma=2.0, scale=1.0,
+            aux=False):
+    z = logits[:, :num_classes].float()
+    n = z.shape[0]
+    logp = F.log_softmax(z, dim=-1)
+    p = logp.exp()
+    w = class_w[labels] if class_w is not None else torch.ones(n)
+    lp_y = logp.gather(1, labels.view(-1, 1)).squeeze(1)
+    p_y = lp_y.exp()
+    if mode == 2:
+        per = -w * (1 - p_y).clamp_min(0) ** gamma * lp_y
+        denom = float(n)
+        f = w * ((1 - p_y).clamp_min(0) ** gamma - gamma * (1 - p_y).clamp_min(0) ** (gamma - 1) * p_y * lp_y)
+    else:
+        per = -w * lp_y
+        denom = float(w.sum()) if mode == 1 else float(n)
+        f = w
+    loss = per.sum() / denom
+    acc = (z.argmax(1) == labels).float().mean()
+    if aux:
+        out[0] += scale * loss
+        if accum is not None:
+            accum[0] += scale * loss
+    else:
+        out[0] = scale * loss
+        out[1] = acc
+        if accum is not None:
+            accum[0] += scale * loss
+            accum[1] += acc
+            accum[2] += 1
+    if dlogits is not None:
+        onehot = F.one_hot(labels, num_classes).float()
+        g = (f / denom * scale).unsqueeze(1) * (p - onehot)
+        dlogits.zero_()
+        dlogits[:, :num_classes] = g.to(dlogits.dtype)
+    return out
+
+
+# ----------------------------------------------------------------------------------------- optimizer
+def adam_step(p, g, m, v, p16, hyper, lo=0, hi=None):
+    hi = p.numel() if hi is None else hi
+    lr, b1, b2, eps, wd, step, _, gs = [float(h) for h in hyper]
+    step += 1
+    gr = g[lo:hi] * gs
+    if wd:
+        gr = gr + wd * p[lo:hi]
+    m[lo:hi].mul_(b1).add_(gr, alpha=1 - b1)
+    v[lo:hi].mul_(b2).addcmul_(gr, gr, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2s = math.sqrt(1 - b2 ** step)
+    denom = v[lo:hi].sqrt() / bc2s + eps
+    p[lo:hi].addcdiv_(m[lo:hi], denom, value=-lr / bc1)
+    if p16 is not None:
+        p16[lo:hi].copy_(p[lo:hi])
+
+
+def sgd_step(p, g, buf, p16, hyper, lo=0, hi=None):
+    hi = p.numel() if hi is None else hi
+    lr, _, _, _, wd, step, mu, gs = [float(h) for h in hyper]
+    gr = g[lo:hi] * gs
+    if wd:
+        gr = gr + wd * p[lo:hi]
+    if mu != 0:
+        if step < 0.5:
+            buf[lo:hi].copy_(gr)
+        else:
+            buf[lo:hi].mul_(mu).add_(gr)
+        gr = buf[lo:hi]
+    p[lo:hi].add_(gr, alpha=-lr)
+    if p16 is not None:
+        p16[lo:hi].copy_(p[lo:hi])
+
+
+def advance_step(hyper):
+    hyper[5] += 1
+
+
+def cast(src, dst):
+    dst.copy_(src)
+    return dst
+
+
+# ----------------------------------------------------------------------------------------- input pipeline
+def augment_mnist(images, labels, index, out, labels_out, train, mean, std, seed, epoch):
+    """CPU stand-in for csrc/hip/augment.hip: same transform family (rotate +-5 deg nearest, random-resized-crop,
+    bilinear resize, normalise, 3-channel repeat), parameters from a torch generator keyed by (seed, epoch, index)."""
+    b = index.numel()
+    s = images.shape[1]
+    d = out.shape[1]
+    idx = index.long()
+    src = images[idx].float()                      # b s s
+    labels_out.copy_(labels[idx])
+    res = torch.empty(b, d, d)
+    for i in range(b):
+        img = src[i]
+        top, left, h, w = 0, 0, s, s
+        if train:
+            g = torch.Generator().manual_seed((int(seed) * 2654435761 + int(epoch) * 97 + int(idx[i])) % (2 ** 63 - 1))
+            r = torch.rand(64, generator=g)
+            ang = float(r[0] * 10 - 5) * math.pi / 180
+            ca, sa = math.cos(ang), math.sin(ang)
+            ys, xs = torch.meshgrid(torch.arange(s) + 0.5 - s / 2, torch.arange(s) + 0.5 - s / 2, indexing="ij")
+            sx = torch.floor(ca * xs - sa * ys + s / 2).long()
+            sy = torch.floor(sa * xs + ca * ys + s / 2).long()
+            ok = (sx >= 0) & (sx < s) & (sy >= 0) & (sy < s)
+            img = torch.where(ok, img[sy.clamp(0, s - 1), sx.clamp(0, s - 1)], torch.zeros(()))
+            for a in range(10):
+                ta = s * s * (0.08 + 0.92 * float(r[1 + 4 * a]))
+                ar = math.exp(math.log(3 / 4) + (math.log(4 / 3) - math.log(3 / 4)) * float(r[2 + 4 * a]))
+                cw, ch = int(round(math.sqrt(ta * ar))), int(round(math.sqrt(ta / ar)))
+                if 0 < cw <= s and 0 < ch <= s:
+                    top = int(float(r[3 + 4 * a]) * (s - ch + 1))
+                    left = int(float(r[4 + 4 * a]) * (s - cw + 1))
+                    h, w = ch, cw
+                    break
+        crop = img[top:top + h, left:left + w]
+        res[i] = F.interpolate(crop[None, None], size=(d, d), mode="bilinear", align_corners=False)[0, 0]
+    res = (res / 255.0 - mean) / std
+    out.zero_()
+    out[..., :3] = res.unsqueeze(-1).to(out.dtype)
+    return out

@@ -1,0 +1,264 @@
+"""T2 kernel correctness: every non-conv HIP kernel against the plain-PyTorch fp32 reference of the same op
+(ops/ref_ops.py run on CPU copies of the same inputs)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return (1e-4, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+def _rand(shape, dtype, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 14, 14, 64), (2, 7, 9, 24), (3, 5, 5, 2048)])
+def test_bn_forward_backward(shape, dtype):
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    c = shape[3]
+    m = shape[0] * shape[1] * shape[2]
+    x = _rand(shape, dtype, 1, 2.0) + 0.5
+    res = _rand(shape, dtype, 2)
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c)
+    outs = {}
+    for name, O, dev in (("ref", R, "cpu"), ("hip", H, "cuda")):
+        xd, rd = x.to(dev), res.to(dev)
+        g, b = gamma.to(dev), beta.to(dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+        rows = O.bn_slab_rows(m)
+        slab = torch.zeros(rows, 2, c, device=dev)
+        O.bn_stats(xd, slab)
+        mean, invstd, scale, shift = (torch.zeros(c, device=dev) for _ in range(4))
+        O.bn_finalize(slab, m, g, b, rm, rv, nbt, 0.1, 1e-5, mean, invstd, scale, shift)
+        y = torch.empty_like(xd)
+        O.bn_apply(xd, scale, shift, y, residual=rd, relu=True)
+        dy = _rand(shape, dtype, 3).to(dev)
+        dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        sums = torch.zeros(2, c, device=dev)
+        O.bn_bwd_reduce(dy, y, xd, mean, invstd, dg, db, sums)
+        dx = torch.empty_like(xd)
+        O.bn_bwd_dx(dy, xd, mean, invstd, g, sums, dx)
+        outs[name] = [t.float().cpu() for t in (mean, invstd, rm, rv, y, dy, dg, db, dx)] + [nbt.cpu()]
+    rtol, atol = _tol(dtype)
+    names = "mean invstd rm rv y dz dgamma dbeta dx nbt".split()
+    for n, a, b in zip(names, outs["hip"], outs["ref"]):
+        sc = max(1.0, float(b.abs().max())) if n in ("dgamma", "dbeta", "dx") else 1.0
+        torch.testing.assert_close(a, b, rtol=rtol * 5, atol=atol * 5 * sc, msg=lambda s, n=n: f"{n}: {s}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_eval_and_channel_slices(dtype):
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    buf = _rand((2, 6, 6, 64), dtype, 5)
+    c = 32
+    gamma, beta, rm, rv = torch.rand(c) + 0.5, torch.randn(c), torch.randn(c), torch.rand(c) + 0.5
+    res = {}
+    for name, O, dev in (("ref", R, "cpu"), ("hip", H, "cuda")):
+        b = buf.to(dev)
+        x = b[..., 16:48]
+        scale, shift = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+        O.bn_eval_coeffs(gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), 1e-5, scale, shift)
+        outb = torch.zeros(2, 6, 6, 96, device=dev, dtype=dtype)
+        O.bn_apply(x, scale, shift, outb[..., 64:96], relu=False)
+        res[name] = outb.float().cpu()
+    rtol, atol = _tol(dtype)
+    torch.testing.assert_close(res["hip"], res["ref"], rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [((2, 112, 112, 64), 3, 2, 1, False), ((2, 55, 55, 64), 3, 2, 0, False),
+                                 ((2, 109, 109, 96), 3, 2, 0, True), ((2, 14, 14, 512), 2, 2, 0, False)])
+def test_maxpool(cfg, dtype):
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    shape, k, s, p, ceil = cfg
+    n, h, w, c = shape
+    ho, wo = R.pool_out_size(h, k, s, p, ceil), R.pool_out_size(w, k, s, p, ceil)
+    x = _rand(shape, dtype, 1).clamp_min(0)     # post-ReLU-like input with ties at zero
+    dy = _rand((n, ho, wo, c), dtype, 2)
+    res = {}
+    for name, O, dev in (("ref", R, "cpu"), ("hip", H, "cuda")):
+        xd = x.to(dev)
+        y = torch.empty(n, ho, wo, c, device=dev, dtype=dtype)
+        idx = torch.empty(n, ho, wo, c, device=dev, dtype=torch.uint8)
+        O.maxpool_fwd(xd, y, idx, (k, k), (s, s), (p, p))
+        dx = torch.empty_like(xd)
+        O.maxpool_bwd(dy.to(dev), idx, dx, (k, k), (s, s), (p, p))
+        res[name] = (y.float().cpu(), dx.float().cpu())
+    torch.testing.assert_close(res["hip"][0], res["ref"][0], rtol=0, atol=0)
+    ref_nchw = torch.nn.functional.max_pool2d(x.float().permute(0, 3, 1, 2), k, s, p, ceil_mode=ceil).permute(0, 2, 3, 1)
+    torch.testing.assert_close(res["hip"][0], ref_nchw, rtol=0, atol=0)
+    # total gradient mass is conserved; exact tie-breaking may differ from the unfold-based reference
+    rtol, atol = _tol(dtype)
+    torch.testing.assert_close(res["hip"][1].sum((1, 2)), res["ref"][1].sum((1, 2)), rtol=rtol * 10, atol=atol * 50)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [((2, 7, 7, 512), None, None, 0, (1, 1)), ((2, 13, 13, 256), None, None, 0, (6, 6)),
+                                 ((2, 14, 14, 512), None, None, 0, (7, 7)), ((2, 28, 28, 128), 2, 2, 0, None),
+                                 ((2, 17, 17, 768), 5, 3, 0, None), ((2, 35, 35, 192), 3, 1, 1, None)])
+def test_avgpool(cfg, dtype):
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    shape, k, s, p, adaptive = cfg
+    n, h, w, c = shape
+    if adaptive:
+        ho, wo = adaptive
+        ks = st = None
+    else:
+        ho, wo = R.pool_out_size(h, k, s, p), R.pool_out_size(w, k, s, p)
+        ks, st = (k, k), (s, s)
+    x = _rand(shape, dtype, 1)
+    dy = _rand((n, ho, wo, c), dtype, 2)
+    res = {}
+    for name, O, dev in (("ref", R, "cpu"), ("hip", H, "cuda")):
+        xd = x.to(dev)
+        y = torch.empty(n, ho, wo, c, device=dev, dtype=dtype)
+        O.avgpool_fwd(xd, y, ks, st, (p, p), adaptive=bool(adaptive))
+        dx = torch.empty_like(xd)
+        O.avgpool_bwd(dy.to(dev), dx, ks, st, (p, p), adaptive=bool(adaptive))
+        res[name] = (y.float().cpu(), dx.float().cpu())
+    rtol, atol = _tol(dtype)
+    torch.testing.assert_close(res["hip"][0], res["ref"][0], rtol=rtol, atol=atol)
+    torch.testing.assert_close(res["hip"][1], res["ref"][1], rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("nc", [(64, 10), (37, 1000)])
+def test_ce_loss(nc, mode, dtype):
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    n, c = nc
+    ld = (c + 7) // 8 * 8
+    z = _rand((n, ld), dtype, 1, 3.0)
+    labels = torch.randint(0, c, (n,), generator=torch.Generator().manual_seed(3))
+    cw = torch.rand(c) + 0.5
+    res = {}
+    for name, O, dev in (("ref", R, "cpu"), ("hip", H, "cuda")):
+        out = torch.zeros(2, device=dev)
+        accum = torch.zeros(3, device=dev)
+        dl = torch.full((n, ld), 7.0, device=dev, dtype=dtype)
+        O.ce_loss(z.to(dev), labels.to(dev), c, out, accum=accum, dlogits=dl, class_w=cw.to(dev) if mode else None,
+                  mode=mode, scale=1.0)
+        O.ce_loss(z.to(dev), labels.to(dev), c, out, accum=accum, dlogits=None, class_w=cw.to(dev) if mode else None,
+                  mode=mode, scale=0.4, aux=True)
+        res[name] = (out.cpu(), accum.cpu(), dl.float().cpu())
+    # oracle for the loss value itself
+    zf = z[:, :c].float()
+    if mode == 0:
+        expect = torch.nn.functional.cross_entropy(zf, labels)
+    elif mode == 1:
+        expect = torch.nn.functional.cross_entropy(zf, labels, weight=cw)
+    else:
+        lp = torch.log_softmax(zf, -1)
+        expect = torch.nn.functional.nll_loss(((1 - lp.exp()) ** 2) * lp, labels, weight=cw, reduction="none").mean()
+    torch.testing.assert_close(res["ref"][0][0], expect * 1.4, rtol=1e-4, atol=1e-5)
+    rtol, atol = _tol(dtype)
+    for a, b in zip(res["hip"], res["ref"]):
+        torch.testing.assert_close(a, b, rtol=max(rtol, 1e-3), atol=atol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise_and_colsum(dtype):
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    a, b = _rand((3, 9, 9, 40), dtype, 1), _rand((3, 9, 9, 40), dtype, 2)
+    res = {}
+    for name, O, dev in (("ref", R, "cpu"), ("hip", H, "cuda")):
+        ad, bd = a.to(dev), b.to(dev)
+        s = torch.empty_like(ad)
+        O.add(ad, bd, s)
+        r = torch.empty_like(ad)
+        O.relu_fwd(ad, r)
+        g = bd.clone()
+        O.relu_bwd(g, r)
+        cs = torch.ones(40, device=dev)
+        O.colsum(ad, cs, accumulate=True)
+        big = _rand((4, 40, 40, 16), dtype, 4).to(dev)
+        cs2 = torch.zeros(16, device=dev)
+        O.colsum(big, cs2)
+        w = _rand((24, 3, 3, 16), dtype, 5).to(dev)
+        wt = torch.empty(16, 3, 3, 24, device=dev, dtype=dtype)
+        O.transpose_krsc(w, wt)
+        res[name] = [t.float().cpu() for t in (s, r, g, cs, cs2, wt)]
+    rtol, atol = _tol(dtype)
+    for x, y in zip(res["hip"], res["ref"]):
+        torch.testing.assert_close(x, y, rtol=rtol, atol=atol * 20)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_mask_regenerates(dtype):
+    from distributedpytorch_amd.ops import hip_ops as H
+    x = torch.ones(8, 1, 1, 4096, device="cuda", dtype=dtype)
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    H.dropout(x, y1, 0.5, rng, 3)
+    H.dropout(x, y2, 0.5, rng, 3)
+    assert torch.equal(y1, y2)                          # backward regenerates the same mask
+    keep = (y1 != 0).float().mean().item()
+    assert 0.47 < keep < 0.53
+    assert set(y1.float().unique().tolist()) <= {0.0, 2.0}
+    H.rng_advance(rng)
+    H.dropout(x, y2, 0.5, rng, 3)
+    assert not torch.equal(y1, y2)                      # next step, new mask
+    y3 = torch.empty_like(x)
+    H.dropout(x, y3, 0.5, rng, 4)
+    assert not torch.equal(y2, y3)                      # other layer, other mask
+
+
+def test_optimizers_match_torch():
+    from distributedpytorch_amd.ops import hip_ops as H
+    n = 10_007
+    for kind in ("adam", "sgd"):
+        p0, g0 = torch.randn(n), torch.randn(n)
+        p = p0.cuda()
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        p16 = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+        hyper = torch.tensor([1e-3, .9, .999, 1e-8, 0., 0., 0.9, 0.5], device="cuda")
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([ref], lr=1e-3) if kind == "adam" else torch.optim.SGD([ref], lr=1e-3, momentum=0.9)
+        for it in range(4):
+            g = (g0 * (it + 1)).cuda()
+            if kind == "adam":
+                H.adam_step(p, g * 2, m, v, p16, hyper)          # grad_scale 0.5 folds the DDP 1/world
+            else:
+                H.sgd_step(p, g * 2, m, p16, hyper)
+            H.advance_step(hyper)
+            ref.grad = g0 * (it + 1)
+            opt.step()
+        torch.testing.assert_close(p.cpu(), ref.data, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(p16.float().cpu(), ref.data.bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_augment_mnist(dtype):
+    from distributedpytorch_amd.ops import hip_ops as H
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    images = torch.randint(0, 256, (50, 28, 28), generator=g, dtype=torch.uint8)
+    labels = torch.randint(0, 10, (50,), generator=g)
+    idx = torch.tensor([3, 7, 49, 0], dtype=torch.int32)
+    cpad = 8
+    out = torch.full((4, 224, 224, cpad), float("nan"), device="cuda", dtype=dtype)
+    lab = torch.zeros(4, dtype=torch.int64, device="cuda")
+    # eval transform == bilinear resize + normalise + 3-channel repeat: exact oracle
+    H.augment_mnist(images.cuda(), labels.cuda(), idx.cuda(), out, lab, False, 0.1307, 0.3081, 1234, 0)
+    ref = F.interpolate(images[idx.long()].float()[:, None], size=(224, 224), mode="bilinear", align_corners=False)[:, 0]
+    ref = (ref / 255 - 0.1307) / 0.3081
+    rtol, atol = _tol(dtype)
+    for ch in range(3):
+        torch.testing.assert_close(out[..., ch].float().cpu(), ref, rtol=rtol, atol=atol * 10)
+    assert out[..., 3:].abs().max().item() == 0
+    assert torch.equal(lab.cpu(), labels[idx.long()])
+    # train transform: deterministic in (seed, epoch, index), changes with the epoch, stays in range
+    o1, o2, o3 = (torch.empty_like(out) for _ in range(3))
+    H.augment_mnist(images.cuda(), labels.cuda(), idx.cuda(), o1, lab, True, 0.1307, 0.3081, 1234, 0)
+    H.augment_mnist(images.cuda(), labels.cuda(), idx.cuda(), o2, lab, True, 0.1307, 0.3081, 1234, 0)
+    H.augment_mnist(images.cuda(), labels.cuda(), idx.cuda(), o3, lab, True, 0.1307, 0.3081, 1234, 1)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    lo, hi = (0 - 0.1307) / 0.3081, (1 - 0.1307) / 0.3081
+    assert o1[..., 0].float().min().item() >= lo - 0.05 and o1[..., 0].float().max().item() <= hi + 0.05
