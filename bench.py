@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): train images/sec of ResNet-50 on synthetic ImageNet-shape 224x224 data,
+large per-GPU batch, data-parallel over N MI355X of one node (RCCL over xGMI), weak scaling.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Every timed step is a full training iteration: forward, fused loss, hand-written backward, bucketed gradient
+all-reduce overlapped with backward, fused Adam update (the reference's default optimizer, classif.py:124).
+Rank 0 prints ONE JSON line; `value` is the whole-job images/sec (max step time over ranks).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet"])
+    ap.add_argument("--shape", default="imagenet", choices=["imagenet", "cifar", "mnist"])
+    ap.add_argument("--dtype", default=os.environ.get("DPA_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "SGD"])
+    ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU only)")
+    ap.add_argument("--no-broadcast-buffers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "bench.py needs an MI355X (no GPU visible)"}))
+        return 2
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.parallel import comm
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        comm.init_process_group(rank, world, device)
+
+    torch.manual_seed(1234)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    shapes = {"imagenet": (224, 1000, False), "cifar": (32, 10, True), "mnist": (224, 10, False)}
+    side, classes, small = shapes[args.shape]
+    net, _ = get_model(args.model, classes, device=device, dtype=dtype, small_input=small)
+    opt = ArenaOptimizer(net.store, args.optimizer, lr=1e-3)
+    dm = DistributedModel(net, Criterion("cross_entropy"), opt, bucket_cap_mb=args.bucket_mb,
+                          broadcast_buffers=not args.no_broadcast_buffers)
+
+    # synthetic, device-resident batch (NHWC, 3 real channels padded to the kernels' 8-channel granule)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.zeros(args.batch, side, side, net.in_channels, device=device, dtype=dtype)
+    x[..., :3] = torch.randn(args.batch, side, side, 3, device=device, generator=g).to(dtype)
+    y = torch.randint(0, classes, (args.batch,), device=device, generator=g)
+
+    use_graph = args.graph and world == 1
+    if use_graph:
+        dm.capture_train_step(x, y, warmup=max(args.warmup, 2))
+        step = lambda: dm.replay_train_step(x, y)      # noqa: E731
+    else:
+        step = lambda: dm.train_step(x, y)             # noqa: E731
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss, acc, iters = dm.epoch_metrics()
+
+    if rank == 0:
+        global_batch = args.batch * world
+        ips = global_batch * args.steps / elapsed
+        print(json.dumps({
+            "metric": "train images/sec (node), ResNet-50 synthetic ImageNet-shape 224x224, DDP" if args.model == "resnet50"
+            else f"train images/sec (node), {args.model} synthetic {args.shape}-shape, DDP",
+            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, device-resident batch)",
+            "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch, "seq_len": None,
+                       "image": f"{side}x{side}x3", "classes": classes, "optimizer": args.optimizer,
+                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "hipgraph": use_graph,
+                       "mean_loss": round(loss, 4)},
+        }), flush=True)
+    if world > 1:
+        comm.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

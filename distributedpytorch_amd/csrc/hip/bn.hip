@@ -101,28 +101,45 @@ __global__ void __launch_bounds__(64) bn_eval_coeffs_kernel(int C, const float* 
   shift_out[c] = b - rm[c] * g * invstd;
 }
 
+// Column-persistent elementwise layout shared by bn_apply / bn_bwd_dx: a thread owns ONE 16-byte channel chunk and
+// walks rows, so the per-channel coefficients are loaded once into registers (the first version re-loaded 2-5 fp32
+// vectors per element and was texture-address bound: 410 us vs 53 us for the same bytes, profiles/README.md).
 template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, int x_cs, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int r_cs,
-                                                       T* __restrict__ y, int y_cs, long long M, int C, int relu) {
+                                                       T* __restrict__ y, int y_cs, long long M, int C, int relu,
+                                                       int rowsPerBlock) {
   constexpr int VEC = 16 / sizeof(T);
   const int cpr = C / VEC;
-  const long long total = M * cpr;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const long long m = i / cpr;
-    const int c = (int)(i - m * cpr) * VEC;
-    Vec16<T> v; v.load(x + m * x_cs + c);
-    Vec16<T> rv; if (res) rv.load(res + m * r_cs + c);
-    Vec16<T> o;
+  const int colsPerPass = cpr < 256 ? cpr : 256;
+  const int rowLanes = 256 / colsPerPass;
+  const int col = threadIdx.x % colsPerPass, rl = threadIdx.x / colsPerPass;
+  if (rl >= rowLanes) return;
+  const long long r0 = (long long)blockIdx.x * rowsPerBlock;
+  long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
+  for (int cb = col; cb < cpr; cb += colsPerPass) {
+    const int c = cb * VEC;
+    float sc[VEC], sh[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float f = v.get(e) * scale[c + e] + shift[c + e];
-      if (res) f += rv.get(e);
-      if (relu) f = fmaxf(f, 0.f);
-      o.set(e, f);
+    for (int e = 0; e < VEC; e += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(scale + c + e);
+      const float4 b = *reinterpret_cast<const float4*>(shift + c + e);
+      sc[e] = a.x; sc[e + 1] = a.y; sc[e + 2] = a.z; sc[e + 3] = a.w;
+      sh[e] = b.x; sh[e + 1] = b.y; sh[e + 2] = b.z; sh[e + 3] = b.w;
     }
-    o.store(y + m * y_cs + c);
+    for (long long m = r0 + rl; m < r1; m += rowLanes) {
+      Vec16<T> v; v.load(x + m * x_cs + c);
+      Vec16<T> rv; if (res) rv.load(res + m * r_cs + c);
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float f = v.get(e) * sc[e] + sh[e];
+        if (res) f += rv.get(e);
+        if (relu) f = fmaxf(f, 0.f);
+        o.set(e, f);
+      }
+      o.store(y + m * y_cs + c);
+    }
   }
 }
 
@@ -180,10 +197,15 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(T* __restrict__ dy, 
   }
 }
 
-// slab [rows][2][C] -> dbeta = sum dz, dgamma = sum dz*xhat (written or accumulated into the fp32 grad arena)
+// slab [rows][2][C] -> dbeta = sum dz, dgamma = sum dz*xhat (written or accumulated into the fp32 grad arena) and the
+// folded per-channel coefficients of dx = A*dz + B*x + D  (coef[0..3C) = A | B | D):
+//   A = gamma*invstd   B = -gamma*invstd^2*dgamma/M   D = -A*dbeta/M - B*mean
 __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ slab, int rows, int C,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ sums, int accumulate) {
+                                                             float* __restrict__ sums, int accumulate,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, float invM,
+                                                             float* __restrict__ coef) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   float s = 0.f, q = 0.f;
@@ -191,35 +213,52 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __rest
   sums[c] = s; sums[C + c] = q;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + q : q;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s : s;
+  const float g = gamma ? gamma[c] : 1.f, is = invstd[c];
+  const float A = g * is, B = -g * is * is * q * invM;
+  coef[c] = A; coef[C + c] = B; coef[2 * C + c] = -A * s * invM - B * mean[c];
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz, int dz_cs, const T* __restrict__ x, int x_cs,
-                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                        T* __restrict__ dx, int dx_cs, long long M, int C) {
+__global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz, int dz_cs, const T* x, int x_cs,
+                                                        const float* __restrict__ coef, T* dx, int dx_cs,
+                                                        long long M, int C, int rowsPerBlock) {
   constexpr int VEC = 16 / sizeof(T);
   const int cpr = C / VEC;
-  const long long total = M * cpr;
-  const float invM = 1.0f / (float)M;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const long long m = i / cpr;
-    const int c = (int)(i - m * cpr) * VEC;
-    Vec16<T> g; g.load(dz + m * dz_cs + c);
-    Vec16<T> xv; xv.load(x + m * x_cs + c);
-    Vec16<T> o;
+  const int colsPerPass = cpr < 256 ? cpr : 256;
+  const int rowLanes = 256 / colsPerPass;
+  const int col = threadIdx.x % colsPerPass, rl = threadIdx.x / colsPerPass;
+  if (rl >= rowLanes) return;
+  const long long r0 = (long long)blockIdx.x * rowsPerBlock;
+  long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
+  for (int cb = col; cb < cpr; cb += colsPerPass) {
+    const int c = cb * VEC;
+    float A[VEC], B[VEC], D[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float is = invstd[c + e];
-      const float xh = (xv.get(e) - mean[c + e]) * is;
-      const float gm = gamma ? gamma[c + e] : 1.f;
-      o.set(e, gm * is * (g.get(e) - sums[c + e] * invM - xh * sums[C + c + e] * invM));
+    for (int e = 0; e < VEC; e += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(coef + c + e);
+      const float4 b = *reinterpret_cast<const float4*>(coef + C + c + e);
+      const float4 d = *reinterpret_cast<const float4*>(coef + 2 * C + c + e);
+      A[e] = a.x; A[e + 1] = a.y; A[e + 2] = a.z; A[e + 3] = a.w;
+      B[e] = b.x; B[e + 1] = b.y; B[e + 2] = b.z; B[e + 3] = b.w;
+      D[e] = d.x; D[e + 1] = d.y; D[e + 2] = d.z; D[e + 3] = d.w;
     }
-    o.store(dx + m * dx_cs + c);
+    for (long long m = r0 + rl; m < r1; m += rowLanes) {
+      Vec16<T> g; g.load(dz + m * dz_cs + c);
+      Vec16<T> xv; xv.load(x + m * x_cs + c);   // dx may alias x: each thread reads its chunk before writing it
+      Vec16<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.set(e, A[e] * g.get(e) + B[e] * xv.get(e) + D[e]);
+      o.store(dx + m * dx_cs + c);
+    }
   }
 }
 
+static int ew_rows_per_block(long long M, int* nblocks) {
+  long long rpb = (M + 2047) / 2048;
+  if (rpb < 16) rpb = 16;
+  *nblocks = (int)((M + rpb - 1) / rpb);
+  return (int)rpb;
+}
 static int rows_per_block(long long M, int* nblocks) {
   long long rpb = (M + 1023) / 1024;
   if (rpb < 8) rpb = 8;
@@ -257,17 +296,17 @@ DPA_API void dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, co
 }
 DPA_API void dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
                           int y_cs, long long M, int C, int relu, int dtype, hipStream_t s) {
-  const int vec = dtype == 1 ? 8 : 4;
-  const int grid = dpa_grid(M * (C / vec), 256);
-  if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
-                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu);
-  else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
-                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu);
+  int nb; const int rpb = ew_rows_per_block(M, &nb);
+  if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
+                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb);
+  else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
+                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu, rpb);
 }
-// slab: >= dpa_bn_slab_rows(M)*2*C floats; scratch >= ROWS_L2*2*C; sums: 2*C floats (kept for bn_bwd_dx)
+// slab: >= dpa_bn_slab_rows(M)*2*C floats; scratch >= ROWS_L2*2*C; sums: 2*C floats; coef: 3*C floats (for bn_bwd_dx)
 DPA_API void dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, const void* x, int x_cs, const float* mean,
-                               const float* invstd, long long M, int C, float* slab, float* scratch, float* dgamma,
-                               float* dbeta, float* sums, int accumulate, int dtype, hipStream_t s) {
+                               const float* invstd, const float* gamma, long long M, int C, float* slab, float* scratch,
+                               float* dgamma, float* dbeta, float* sums, float* coef, int accumulate, int dtype,
+                               hipStream_t s) {
   int nb; const int rpb = rows_per_block(M, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (bf16_t*)dy, dy_cs, (const bf16_t*)y,
                                      y_cs, (const bf16_t*)x, x_cs, mean, invstd, M, C, slab, rpb);
@@ -275,17 +314,16 @@ DPA_API void dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, con
                                      y_cs, (const float*)x, x_cs, mean, invstd, M, C, slab, rpb);
   int rows = nb;
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
+                     mean, invstd, gamma, 1.0f / (float)M, coef);
 }
-DPA_API void dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* mean, const float* invstd,
-                           const float* gamma, const float* sums, void* dx, int dx_cs, long long M, int C, int dtype,
-                           hipStream_t s) {
-  const int vec = dtype == 1 ? 8 : 4;
-  const int grid = dpa_grid(M * (C / vec), 256);
-  if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
-                                     (const bf16_t*)x, x_cs, mean, invstd, gamma, sums, (bf16_t*)dx, dx_cs, M, C);
-  else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dz, dz_cs,
-                                     (const float*)x, x_cs, mean, invstd, gamma, sums, (float*)dx, dx_cs, M, C);
+DPA_API void dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
+                           long long M, int C, int dtype, hipStream_t s) {
+  int nb; const int rpb = ew_rows_per_block(M, &nb);
+  if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
+                                     (const bf16_t*)x, x_cs, coef, (bf16_t*)dx, dx_cs, M, C, rpb);
+  else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, dz_cs,
+                                     (const float*)x, x_cs, coef, (float*)dx, dx_cs, M, C, rpb);
 }
 
 // Per-channel column sum of a tall activation (conv bias gradients): stats slab -> fixed-order reduce.

@@ -136,10 +136,10 @@ class BatchNorm2d:
         self._aux = None
 
     def aux(self, device):
-        """Persistent per-layer fp32 vectors: mean, invstd, scale, shift, sums[2]."""
+        """Persistent per-layer fp32 vectors: mean, invstd, scale, shift, sums[2], coef[3]."""
         if self._aux is None:
             cp = pad_to(self.c)
-            self._aux = torch.zeros(6, cp, device=device)
+            self._aux = torch.zeros(9, cp, device=device)
         return self._aux
 
     def coeffs(self, ctx: Context, slab, count):
@@ -160,11 +160,11 @@ class BatchNorm2d:
         a = self.aux(ctx.device)
         dg = st.gview(self.gamma) if self.trainable else None
         db = st.gview(self.beta) if self.trainable else None
-        ops.bn_bwd_reduce(dy, y_for_mask, z, a[0], a[1], dg, db, a[4:6])
+        ops.bn_bwd_reduce(dy, y_for_mask, z, a[0], a[1], st.view(self.gamma), dg, db, a[4:6], a[6:9])
         if self.trainable:
             ctx.tape.ready(self.gamma)
             ctx.tape.ready(self.beta)
-        ops.bn_bwd_dx(dy, z, a[0], a[1], st.view(self.gamma), a[4:6], dx_out)
+        ops.bn_bwd_dx(dy, z, a[6:9], dx_out)
         return dx_out
 
 

@@ -131,11 +131,13 @@ def bn_apply(x, scale, shift, y, residual=None, relu=False):
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, dgamma, dbeta, sums, slab=None, scratch=None, accumulate=False):
-    """Masks dy in place by (y > 0) when y is given; writes sums[0]=sum dz, sums[1]=sum dz*xhat; dgamma/dbeta."""
+def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab=None, scratch=None, accumulate=False):
+    """Masks dy in place by (y > 0) when y is given; sums[0]=sum dz, sums[1]=sum dz*xhat; dgamma/dbeta; coef = the
+    folded per-channel (A, B, D) of dx = A*dz + B*x + D consumed by bn_bwd_dx."""
     if y is not None:
         dy.mul_((y > 0).to(dy.dtype))
     dz = dy.float().reshape(-1, dy.shape[-1])
+    m = dz.shape[0]
     xh = (x.float().reshape(-1, x.shape[-1]) - mean) * invstd
     s = dz.sum(0)
     q = (dz * xh).sum(0)
@@ -151,13 +153,16 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, dgamma, dbeta, sums, slab=None, scratc
             dbeta.add_(s)
         else:
             dbeta.copy_(s)
+    g = gamma if gamma is not None else torch.ones_like(mean)
+    a = g * invstd
+    b = -g * invstd * invstd * q / m
+    coef[0].copy_(a)
+    coef[1].copy_(b)
+    coef[2].copy_(-a * s / m - b * mean)
 
 
-def bn_bwd_dx(dz, x, mean, invstd, gamma, sums, dx):
-    m = dz.numel() // dz.shape[-1]
-    xh = (x.float() - mean) * invstd
-    g = gamma if gamma is not None else 1.0
-    out = g * invstd * (dz.float() - sums[0] / m - xh * sums[1] / m)
+def bn_bwd_dx(dz, x, coef, dx):
+    out = coef[0] * dz.float() + coef[1] * x.float() + coef[2]
     dx.copy_(out.to(dx.dtype))
     return dx
 

@@ -1,0 +1,97 @@
+"""One training / evaluation iteration of the reference's hot loop (/root/reference/classif.py:41-62) on the engine:
+forward -> fused loss+accuracy -> hand-written backward with bucketed all-reduce overlapped -> fused optimizer.
+No host synchronisation happens inside: loss/accuracy accumulate on the device (K16) and are read at log points.
+
+`graph=True` captures the whole iteration (forward, backward, optimizer) into a hipGraph after a warm-up, which
+removes the per-kernel launch cost that dominates small-batch MNIST steps.  Collectives are
+not captured: graphs are used for world_size == 1 or for the forward/backward body only when requested.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..nn.engine import Tape
+from ..nn.loss import Criterion
+from ..nn.optim import ArenaOptimizer
+from .reducer import GradReducer
+
+
+class DistributedModel:
+    """The DDP-wrapped model + optimizer: owns the reducer and the device-side metric accumulators."""
+
+    def __init__(self, net, criterion: Criterion, optimizer: ArenaOptimizer = None, first_bucket_mb=1.0,
+                 bucket_cap_mb=25.0, broadcast_buffers=True, sync_comm=False):
+        self.net, self.criterion, self.opt = net, criterion, optimizer
+        dev = net.store.device
+        self.device = dev
+        self.reducer = None
+        if optimizer is not None:
+            self.reducer = GradReducer(net.store, optimizer, first_bucket_mb, bucket_cap_mb, broadcast_buffers,
+                                       sync_mode=sync_comm)
+        self.metrics = torch.zeros(2, device=dev)          # last-iteration (loss, acc)
+        self.accum = torch.zeros(3, device=dev)            # epoch sums: loss, acc, iterations
+        self._graph = None
+        self._static_x = self._static_y = None
+
+    # ------------------------------------------------------------------ eager iteration
+    def _forward_loss(self, x, labels, tape):
+        ctx, out = self.net.forward(x, tape)
+        if isinstance(out, tuple):                          # inception in train mode: loss = main + 0.4 * aux
+            main, aux = out
+            self.criterion(ctx, main, labels, self.net.num_classes, self.metrics, accum=self.accum)
+            self.criterion(ctx, aux, labels, self.net.num_classes, self.metrics, accum=self.accum, scale=0.4, aux=True)
+        else:
+            self.criterion(ctx, out, labels, self.net.num_classes, self.metrics, accum=self.accum)
+        return ctx
+
+    def train_step(self, x, labels):
+        """x: NHWC compute-dtype batch on the device; labels: int64 on the device."""
+        net, red = self.net, self.reducer
+        net.train()
+        red.sync_buffers()
+        tape = Tape()
+        tape.param_ready_hook = red.param_ready
+        red.begin_backward()
+        self._forward_loss(x, labels, tape)
+        tape.backward()
+        red.finish_and_step()
+        from .. import ops
+        ops.rng_advance(net.rng)
+
+    def eval_step(self, x, labels):
+        self.net.eval()
+        self._forward_loss(x, labels, None)
+
+    # ------------------------------------------------------------------ hipGraph iteration (single-rank body)
+    def capture_train_step(self, x, labels, warmup=3):
+        """Capture forward+backward+optimizer into a hipGraph (world_size == 1).  Returns False if unsupported."""
+        if self.device.type != "cuda" or self.reducer.world != 1:
+            return False
+        self._static_x, self._static_y = x.clone(), labels.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.train_step(self._static_x, self._static_y)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.train_step(self._static_x, self._static_y)
+        self._graph = g
+        return True
+
+    def replay_train_step(self, x, labels):
+        self._static_x.copy_(x, non_blocking=True)
+        self._static_y.copy_(labels, non_blocking=True)
+        self._graph.replay()
+
+    # ------------------------------------------------------------------ metrics (host sync only here)
+    def reset_epoch_metrics(self):
+        self.accum.zero_()
+
+    def epoch_metrics(self):
+        """(mean loss, mean acc, iterations) - one D2H sync."""
+        a = self.accum.tolist()
+        n = max(a[2], 1.0)
+        return a[0] / n, a[1] / n, int(a[2])

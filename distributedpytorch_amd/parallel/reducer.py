@@ -1,0 +1,146 @@
+"""DDP gradient path (N3/N4/N5, X2-X6 of SURVEY.md §2): what c10d::Reducer + DistributedDataParallel do for the
+reference (/root/reference/classif.py:138), rebuilt around the flat gradient arena.
+
+  * gradients already live in ONE arena in registration order, so a bucket is a contiguous slice: no flatten /
+    unflatten copies and no per-parameter views to rebuild;
+  * buckets are planned once, statically, in backward order by the C++ planner (small first bucket, then a cap
+    sized for xGMI: per-peer chunk = bucket/8 should stay >= 1-2 MB);
+  * when the last gradient of a bucket is written the bucket's all-reduce is issued asynchronously on RCCL's stream
+    (torch.distributed orders it after the producing kernels with an event and returns a Work handle), so it
+    overlaps the rest of backward;
+  * after backward each bucket is waited for in order and its fused optimizer update is launched immediately, so the
+    update of bucket k overlaps the all-reduce of bucket k+1; the 1/world_size averaging is folded into the
+    optimizer kernel (no separate divide pass);
+  * wrap-time parameter/buffer broadcast from rank 0 and the per-step BatchNorm buffer broadcast reproduce DDP's
+    semantics (rank 0's running statistics win).
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import logging
+
+import torch
+import torch.distributed as dist
+
+from ..nn.engine import ALIGN, ParamStore, pad_to
+from ..ops import native
+
+DEFAULT_FIRST_BUCKET_MB = 1.0
+DEFAULT_BUCKET_CAP_MB = 25.0
+
+
+def plan_buckets(store: ParamStore, first_mb=DEFAULT_FIRST_BUCKET_MB, cap_mb=DEFAULT_BUCKET_CAP_MB):
+    """Returns a list of buckets in ready order: dict(lo, hi, params=[spec...])."""
+    n = len(store.params)
+    sizes = (ctypes.c_longlong * n)(*[pad_to(s.numel, ALIGN) * 4 for s in store.params])
+    train = (ctypes.c_int * n)(*[int(s.trainable) for s in store.params])
+    out = (ctypes.c_int * n)()
+    nb = native.host_lib().dpa_plan_buckets(sizes, train, n, ctypes.c_longlong(int(first_mb * 2 ** 20)),
+                                            ctypes.c_longlong(int(cap_mb * 2 ** 20)), out)
+    buckets = [dict(lo=None, hi=None, params=[]) for _ in range(nb)]
+    for i, spec in enumerate(store.params):
+        b = out[i]
+        if b < 0:
+            continue
+        bk = buckets[b]
+        lo, hi = spec.offset, spec.offset + pad_to(spec.numel, ALIGN)
+        bk["lo"] = lo if bk["lo"] is None else min(bk["lo"], lo)
+        bk["hi"] = hi if bk["hi"] is None else max(bk["hi"], hi)
+        bk["params"].append(spec)
+    for bk in buckets:
+        covered = sum(pad_to(s.numel, ALIGN) for s in bk["params"])
+        assert covered == bk["hi"] - bk["lo"], "bucket is not a contiguous arena range"
+    return buckets
+
+
+class GradReducer:
+    def __init__(self, store: ParamStore, optimizer, first_mb=DEFAULT_FIRST_BUCKET_MB, cap_mb=DEFAULT_BUCKET_CAP_MB,
+                 broadcast_buffers=True, sync_mode=False, process_group=None):
+        self.store, self.opt = store, optimizer
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
+        self.buckets = plan_buckets(store, first_mb, cap_mb)
+        self.bucket_of = {}
+        for bi, bk in enumerate(self.buckets):
+            for s in bk["params"]:
+                self.bucket_of[s.index] = bi
+        self.broadcast_buffers = broadcast_buffers
+        self.sync_mode = sync_mode            # debug: run every collective synchronously (race detection aid)
+        self._pending = None
+        self._works = None
+        self.comm_bytes = sum((b["hi"] - b["lo"]) * 4 for b in self.buckets)
+        optimizer.set_grad_scale(1.0 / self.world)
+        if self.world > 1:
+            self._verify_and_broadcast()
+
+    # ------------------------------------------------------------------ wrap-time sync (X2, X3)
+    def _verify_and_broadcast(self):
+        sig = hashlib.sha1(repr([(s.name, s.logical_shape, s.trainable) for s in self.store.params]).encode()).digest()[:8]
+        mine = torch.tensor(list(sig), dtype=torch.int64, device=self.store.device)
+        allsig = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allsig, mine, group=self.pg)
+        for r, t in enumerate(allsig):
+            if not torch.equal(t, mine):
+                raise RuntimeError(f"parameter layout differs between rank {self.rank} and rank {r}")
+        dist.broadcast(self.store.p, 0, group=self.pg)
+        dist.broadcast(self.store.b, 0, group=self.pg)
+        dist.broadcast(self.store.nbt, 0, group=self.pg)
+        self.store.refresh_compute_copy()
+
+    # ------------------------------------------------------------------ per step
+    def sync_buffers(self):
+        """DDP's per-forward buffer broadcast (X4): rank 0's BatchNorm running statistics overwrite everyone's."""
+        if self.world > 1 and self.broadcast_buffers and self.store.b_size > 0:
+            dist.broadcast(self.store.b, 0, group=self.pg)
+            dist.broadcast(self.store.nbt, 0, group=self.pg)
+
+    def begin_backward(self):
+        self._pending = [len(b["params"]) for b in self.buckets]
+        self._works = [None] * len(self.buckets)
+
+    def param_ready(self, spec):
+        bi = self.bucket_of.get(spec.index)
+        if bi is None:
+            return
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        bk = self.buckets[bi]
+        sl = self.store.g[bk["lo"]: bk["hi"]]
+        if self.sync_mode:
+            dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            self._works[bi] = dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def finish_and_step(self):
+        """Wait for each bucket in ready order and launch its optimizer update right away."""
+        for bi, bk in enumerate(self.buckets):
+            if self._pending[bi] != 0:
+                raise RuntimeError(f"bucket {bi} never became ready: {self._pending[bi]} gradients missing "
+                                   f"(a trainable parameter did not take part in backward)")
+            w = self._works[bi]
+            if w is not None:
+                w.wait()                       # stream-level wait on GPU; blocks on gloo
+            self.opt.step_range(bk["lo"], bk["hi"])
+        self.opt.finish_step()
+
+    # ------------------------------------------------------------------ diagnostics
+    def check_in_sync(self):
+        """All ranks must hold bit-identical parameters; returns the max deviation of the checksum (0.0 if in sync)."""
+        if self.world == 1:
+            return 0.0
+        cs = torch.stack([self.store.p.double().sum(), self.store.p.double().abs().sum()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        return float((hi - lo).abs().max())
+
+    def describe(self):
+        return [dict(bucket=i, mbytes=(b["hi"] - b["lo"]) * 4 / 2 ** 20, params=len(b["params"])) for i, b in
+                enumerate(self.buckets)]

@@ -42,9 +42,10 @@ def test_bn_forward_backward(shape, dtype):
         dy = _rand(shape, dtype, 3).to(dev)
         dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
         sums = torch.zeros(2, c, device=dev)
-        O.bn_bwd_reduce(dy, y, xd, mean, invstd, dg, db, sums)
+        coef = torch.zeros(3, c, device=dev)
+        O.bn_bwd_reduce(dy, y, xd, mean, invstd, g, dg, db, sums, coef)
         dx = torch.empty_like(xd)
-        O.bn_bwd_dx(dy, xd, mean, invstd, g, sums, dx)
+        O.bn_bwd_dx(dy, xd, coef, dx)
         outs[name] = [t.float().cpu() for t in (mean, invstd, rm, rv, y, dy, dg, db, dx)] + [nbt.cpu()]
     rtol, atol = _tol(dtype)
     names = "mean invstd rm rv y dz dgamma dbeta dx nbt".split()
