@@ -1,0 +1,210 @@
+"""MNIST data pipeline with the reference's structure (/root/reference/dataloader.py:47-180) and an MI355X-first
+execution model: the uint8 dataset (47 MB) is resident in HBM and every batch is produced by ONE fused HIP kernel
+from the sampler's indices (csrc/hip/augment.hip), so no DataLoader workers, no pinned staging and no 38.5 MB H2D
+copy per step (K19/K20 of SURVEY.md).  Preserved semantics: normalisation statistics of the 60 000 training images,
+54 000/6 000 seeded random split (same partition on every rank), train transform = rotate +-5 deg ->
+random-resized-crop -> resize -> 3-channel repeat -> normalise, eval transform = resize -> ... , debug subset of 200
+training samples, one DistributedSampler per phase (shuffled, padded), per-process batch size.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+import math
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..nn.engine import pad_to
+from ..ops import native
+from .sampler import DistributedSampler
+
+VALID_RATIO = 0.9
+FILES = {"train": ("train-images-idx3-ubyte", "train-labels-idx1-ubyte"),
+         "test": ("t10k-images-idx3-ubyte", "t10k-labels-idx1-ubyte")}
+
+
+# ------------------------------------------------------------------------------------------------ IDX files
+def read_idx(path) -> np.ndarray:
+    lib = native.host_lib()
+    dims = (ctypes.c_int * 4)()
+    nd = lib.dpa_idx_header(path.encode(), dims)
+    if nd < 0:
+        raise FileNotFoundError(f"cannot read IDX file {path} (rc={nd})")
+    shape = tuple(dims[i] for i in range(nd))
+    out = np.empty(shape, dtype=np.uint8)
+    lib.dpa_idx_read.restype = ctypes.c_longlong
+    n = lib.dpa_idx_read(path.encode(), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(out.size))
+    if n != out.size:
+        raise IOError(f"short read on {path}: rc={n}")
+    return out
+
+
+def write_idx(path, arr: np.ndarray):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    dims = (ctypes.c_int * arr.ndim)(*arr.shape)
+    rc = native.host_lib().dpa_idx_write(path.encode(), arr.ctypes.data_as(ctypes.c_void_p), dims, arr.ndim)
+    if rc:
+        raise IOError(f"cannot write {path} (rc={rc})")
+
+
+def raw_dir(root):
+    return os.path.join(root, "MNIST", "raw")
+
+
+def have_mnist(root):
+    return all(os.path.exists(os.path.join(raw_dir(root), f)) for pair in FILES.values() for f in pair)
+
+
+def generate_synthetic_mnist(root, n_train=60000, n_test=10000, seed=1234):
+    """Deterministic MNIST-shaped stand-in (there is no network to fetch the real files): ten smooth stroke
+    prototypes, one per class, with per-sample shift, scale jitter and noise, written as the four IDX files
+    torchvision.datasets.MNIST expects under <root>/MNIST/raw."""
+    os.makedirs(raw_dir(root), exist_ok=True)
+    rng = np.random.RandomState(seed)
+    protos = []
+    yy, xx = np.mgrid[0:28, 0:28].astype(np.float32)
+    for c in range(10):
+        img = np.zeros((28, 28), np.float32)
+        pts = rng.uniform(6, 22, size=(4 + c % 3, 2))
+        for a, b in zip(pts[:-1], pts[1:]):
+            for t in np.linspace(0, 1, 24):
+                cy, cx = a + t * (b - a)
+                img += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.3 ** 2))
+        protos.append(np.clip(img / img.max(), 0, 1))
+    protos = np.stack(protos)
+
+    def make(n, rs):
+        labels = rs.randint(0, 10, size=n).astype(np.uint8)
+        imgs = np.empty((n, 28, 28), np.uint8)
+        shifts = rs.randint(-2, 3, size=(n, 2))
+        gains = rs.uniform(0.7, 1.0, size=n).astype(np.float32)
+        for i in range(n):
+            p = np.roll(protos[labels[i]], tuple(shifts[i]), axis=(0, 1)) * gains[i]
+            p = p + rs.normal(0, 0.08, size=(28, 28)).astype(np.float32) * (p > 0.02)
+            imgs[i] = (np.clip(p, 0, 1) * 255).astype(np.uint8)
+        return imgs, labels
+
+    tr_x, tr_y = make(n_train, np.random.RandomState(seed + 1))
+    te_x, te_y = make(n_test, np.random.RandomState(seed + 2))
+    write_idx(os.path.join(raw_dir(root), FILES["train"][0]), tr_x)
+    write_idx(os.path.join(raw_dir(root), FILES["train"][1]), tr_y)
+    write_idx(os.path.join(raw_dir(root), FILES["test"][0]), te_x)
+    write_idx(os.path.join(raw_dir(root), FILES["test"][1]), te_y)
+    logging.info(f"synthetic MNIST written to {raw_dir(root)} ({n_train} train / {n_test} test)")
+
+
+# ------------------------------------------------------------------------------------------------ dataset
+class Subset:
+    """Index view of a split, like torch.utils.data.Subset; carries the class weights the reference assumed (Q10)."""
+
+    def __init__(self, split, indices: torch.Tensor, labels: torch.Tensor, nb_classes):
+        self.split, self.indices = split, indices
+        counts = torch.bincount(labels[indices], minlength=nb_classes).float().clamp_min(1)
+        self.classWeights = len(indices) / (nb_classes * counts)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+class BatchIterator:
+    """One phase's loader: sampler indices -> device index list -> fused augment kernel per batch."""
+
+    def __init__(self, ds, phase):
+        self.ds, self.phase = ds, phase
+
+    def __len__(self):
+        return math.ceil(len(self.ds.sampler[self.phase]) / self.ds.batchSize)
+
+    def __iter__(self):
+        ds, phase = self.ds, self.phase
+        sub = ds.data[phase]
+        local = ds.sampler[phase].indices()
+        gidx = sub.indices[local].to(torch.int32)
+        gidx_dev = gidx.to(ds.device, non_blocking=True)
+        split = sub.split
+        images, labels = ds.images[split], ds.labels[split]
+        train = phase == "train"
+        epoch = ds.sampler[phase].epoch
+        b = ds.batchSize
+        for s in range(0, gidx.numel(), b):
+            idx = gidx_dev[s: s + b]
+            n = idx.numel()
+            x = torch.empty((n, ds.dataDim, ds.dataDim, ds.cpad), device=ds.device, dtype=ds.dtype)
+            y = torch.empty(n, dtype=torch.int64, device=ds.device)
+            ops.augment_mnist(images, labels, idx, x, y, train, ds.mean, ds.std, ds.seed, epoch)
+            yield x, y
+
+
+class MNIST:
+    def __init__(self, dataPath, batchSize, dataDim, worldSize, rank, gpu, device=None, dtype=torch.float32, debug=False,
+                 seed=1234, synthetic_ok=True):
+        self.dataPath, self.batchSize, self.dataDim = dataPath, batchSize, dataDim
+        self.worldSize, self.rank, self.gpu = worldSize, rank, gpu
+        self.device = device if device is not None else torch.device("cuda", gpu) if gpu >= 0 else torch.device("cpu")
+        self.dtype, self.debug, self.seed = dtype, debug, seed
+        self.nbClasses = 10
+        self.cpad = pad_to(3)
+        self.data = {"train": None, "valid": None, "test": None}
+        self.sampler = {"train": None, "valid": None, "test": None}
+        self.iterator = {"train": None, "valid": None, "test": None}
+        self.mean = self.std = 0
+        self.synthetic_ok = synthetic_ok
+        self.loadDataset()
+        self.initIterator()
+        if self.gpu <= 0:
+            logging.info(f"Number of training examples: {len(self.data['train'])}")
+            logging.info(f"Number of validation examples: {len(self.data['valid'])}")
+            logging.info(f"Number of testing examples: {len(self.data['test'])}")
+
+    def loadDataset(self):
+        if not have_mnist(self.dataPath):
+            if not self.synthetic_ok:
+                raise FileNotFoundError(f"MNIST IDX files not found under {raw_dir(self.dataPath)}")
+            # one writer per node; the others wait for the files (same deterministic content on every node)
+            marker = os.path.join(raw_dir(self.dataPath), ".complete")
+            if self.gpu <= 0:
+                generate_synthetic_mnist(self.dataPath, seed=self.seed)
+                open(marker, "w").close()
+            else:
+                import time
+                t0 = time.time()
+                while not os.path.exists(marker):
+                    if time.time() - t0 > 600:
+                        raise TimeoutError("timed out waiting for the synthetic MNIST files")
+                    time.sleep(0.2)
+        raw = raw_dir(self.dataPath)
+        tr_x = torch.from_numpy(read_idx(os.path.join(raw, FILES["train"][0])))
+        tr_y = torch.from_numpy(read_idx(os.path.join(raw, FILES["train"][1]))).long()
+        te_x = torch.from_numpy(read_idx(os.path.join(raw, FILES["test"][0])))
+        te_y = torch.from_numpy(read_idx(os.path.join(raw, FILES["test"][1]))).long()
+        # normalisation statistics over all training images (dataloader.py:94-95)
+        f = tr_x.float()
+        self.mean = float(f.mean() / 255)
+        self.std = float(f.std() / 255)
+        del f
+        self.images = {"train": tr_x.to(self.device), "test": te_x.to(self.device)}
+        self.labels = {"train": tr_y.to(self.device), "test": te_y.to(self.device)}
+        self._labels_cpu = {"train": tr_y, "test": te_y}
+        # random_split([n*0.9, rest]) with the global (seeded) torch RNG: identical partition on every rank
+        n = tr_x.shape[0]
+        n_train = int(n * VALID_RATIO)
+        perm = torch.randperm(n)
+        self.data["train"] = Subset("train", perm[:n_train], tr_y, self.nbClasses)
+        self.data["valid"] = Subset("train", perm[n_train:], tr_y, self.nbClasses)
+        self.data["test"] = Subset("test", torch.arange(te_x.shape[0]), te_y, self.nbClasses)
+
+    def initIterator(self):
+        if self.debug:   # quick test using only 200 training samples (dataloader.py:139-144)
+            sub = self.data["train"]
+            self.data["train"] = Subset(sub.split, sub.indices[:200], self._labels_cpu[sub.split], self.nbClasses)
+        distributed = self.gpu >= 0 or self.worldSize > 1
+        for phase in ("train", "valid", "test"):
+            n = len(self.data[phase])
+            if distributed:
+                self.sampler[phase] = DistributedSampler(n, self.worldSize, self.rank, shuffle=True)
+            else:   # reference CPU path: plain sequential loaders (dataloader.py:171-180)
+                self.sampler[phase] = DistributedSampler(n, 1, 0, shuffle=False)
+            self.iterator[phase] = BatchIterator(self, phase)

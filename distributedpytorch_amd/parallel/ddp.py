@@ -68,6 +68,15 @@ class DistributedModel:
         if self.device.type != "cuda" or self.reducer.world != 1:
             return False
         self._static_x, self._static_y = x.clone(), labels.clone()
+        # warm-up iterations must not perturb training: snapshot every piece of mutable state and restore it
+        st, opt = self.net.store, self.opt
+        state = [st.p, st.b, st.nbt, opt.m, opt.hyper, self.net.rng, self.accum, self.metrics]
+        if opt.v is not None:
+            state.append(opt.v)
+        if st.p16 is not None:
+            state.append(st.p16)
+        saved = [t.clone() for t in state]
+        host_step = opt._host_step
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -79,6 +88,9 @@ class DistributedModel:
         with torch.cuda.graph(g):
             self.train_step(self._static_x, self._static_y)
         self._graph = g
+        for t, sv in zip(state, saved):
+            t.copy_(sv)
+        opt._host_step = host_step
         return True
 
     def replay_train_step(self, x, labels):

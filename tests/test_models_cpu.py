@@ -58,3 +58,83 @@ def test_resnet50_parity():
             if k.endswith("bn3.weight"):
                 v.fill_(0.2)
     _compare("resnet50", oracle, 64, n=8)
+
+
+def _no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def _zero_dropout(net):
+    from distributedpytorch_amd.nn.layers import Dropout
+    def walk(o, seen):
+        if id(o) in seen or isinstance(o, (torch.Tensor, str, int, float, type(None))):
+            return
+        seen.add(id(o))
+        if isinstance(o, Dropout):
+            o.p = 0.0
+        elif isinstance(o, (list, tuple)):
+            for x in o:
+                walk(x, seen)
+        elif isinstance(o, dict):
+            for x in o.values():
+                walk(x, seen)
+        elif hasattr(o, "__dict__") and o.__class__.__module__.startswith("distributedpytorch_amd.models"):
+            for x in vars(o).values():
+                walk(x, seen)
+    walk(net.net, set())
+
+
+def _compare_zoo(name, oracle, hw, n, gtol=2e-2):
+    """Parity with dropout disabled on both sides (masks come from different RNG streams by design)."""
+    torch.manual_seed(0)
+    net, _ = get_model(name, 10, device="cpu")
+    _zero_dropout(net)
+    _no_dropout(oracle)
+    sd = oracle.state_dict()
+    mine = net.state_dict(prefix="")
+    assert list(mine.keys()) == list(sd.keys())
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd)
+    x = torch.randn(n, 3, hw, hw)
+    y = torch.randint(0, 10, (n,))
+    logits, loss, acc = framework_step(net, x, y)
+    oracle = oracle.double()
+    ref_logits, ref_loss = oracle_step(oracle, x.double(), y)
+    torch.testing.assert_close(logits, ref_logits.float(), rtol=2e-3, atol=2e-4)
+    assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    g = grads_by_name(net)
+    gmax = max(p.grad.norm().item() for p in oracle.parameters())
+    for k, p in oracle.named_parameters():
+        v = p.grad.float()
+        err = (g[k] - v).norm().item()
+        # a conv bias followed by BatchNorm has an exactly-zero gradient: only absolute error is meaningful there
+        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax, (k, err, v.norm().item())
+    logits_e, _, _ = framework_step(net, x, y, train=False)
+    ref_e, _ = oracle_step(oracle, x.double(), y, train=False)
+    torch.testing.assert_close(logits_e, ref_e.float(), rtol=2e-3, atol=2e-4)
+
+
+def test_alexnet_parity():
+    _compare_zoo("alexnet", ref.AlexNet(10), 64, 4)
+
+
+def test_vgg11bn_parity():
+    _compare_zoo("vgg", ref.VGG11BN(10), 32, 8)
+
+
+def test_squeezenet_parity():
+    _compare_zoo("squeezenet", ref.SqueezeNet10(10), 64, 4)
+
+
+def test_densenet121_parity():
+    _compare_zoo("densenet", ref.DenseNet121(10), 32, 8)
+
+
+def test_inception_v3_parity():
+    # torch's own fp32 backward differs from its fp64 backward by 2.1 % on this net at batch 4 (ReLU masks and 1x1-spatial
+    # BatchNorm in the aux head are ill-conditioned), so the bound is looser than for the other architectures
+    _compare_zoo("inception", ref.Inception3(10), 299, 4, gtol=8e-2)
