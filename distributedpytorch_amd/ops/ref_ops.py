@@ -367,6 +367,11 @@ def augment_mnist(images, labels, index, out, labels_out, train, mean, std, seed
     idx = index.long()
     src = images[idx].float()                      # b s s
     labels_out.copy_(labels[idx])
+    if not train:        # eval transform has no per-sample parameters: one batched bilinear resize
+        res = F.interpolate(src[:, None], size=(d, d), mode="bilinear", align_corners=False)[:, 0]
+        out.zero_()
+        out[..., :3] = ((res / 255.0 - mean) / std).unsqueeze(-1).to(out.dtype)
+        return out
     res = torch.empty(b, d, d)
     for i in range(b):
         img = src[i]

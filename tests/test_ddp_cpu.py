@@ -1,0 +1,166 @@
+"""T1 plumbing (BASELINE.json config 1): real 2-process data parallelism on CPU over gloo - the same reducer, bucket
+planner and trainer code that runs over RCCL on MI355X."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out_dir, sync_comm):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.parallel import comm
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    from tests.helpers import to_nhwc_padded
+    from tests.test_models_cpu import _zero_dropout
+    torch.set_num_threads(2)
+    comm.init_process_group(rank, world, torch.device("cpu"), timeout_s=120)
+    torch.manual_seed(100 + rank)                     # different init per rank: the wrap-time broadcast must fix it
+    net, _ = get_model("resnet", 10, device="cpu", small_input=True)
+    _zero_dropout(net)
+    opt = ArenaOptimizer(net.store, "adam", lr=1e-3)
+    dm = DistributedModel(net, Criterion(), opt, first_bucket_mb=0.05, bucket_cap_mb=2.0, sync_comm=sync_comm)
+    assert len(dm.reducer.buckets) > 3
+    p0 = net.store.p.clone()
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn(3, 8, 3, 16, 16, generator=g)
+    ys = torch.randint(0, 10, (3, 8), generator=g)
+    grads = []
+    for it in range(3):
+        x = to_nhwc_padded(xs[it, rank * 4:(rank + 1) * 4], torch.float32, "cpu")
+        dm.train_step(x, ys[it, rank * 4:(rank + 1) * 4])
+        grads.append(net.store.g.clone())
+    assert dm.reducer.check_in_sync() == 0.0
+    torch.save({"p0": p0, "p": net.store.p.clone(), "b": net.store.b.clone(), "g": grads, "loss": dm.epoch_metrics()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    comm.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync_comm", [False, True])
+def test_ddp_gloo_two_ranks(tmp_path, sync_comm):
+    world = 2
+    mp.spawn(_ddp_worker, nprocs=world, args=(world, _free_port(), str(tmp_path), sync_comm), join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["p0"], r1["p0"])                  # X3: rank 0's parameters were broadcast at wrap time
+    assert torch.equal(r0["p"], r1["p"])                    # identical parameters after 3 steps
+    assert not torch.equal(r0["p"], r0["p0"])
+    for a, b in zip(r0["g"], r1["g"]):
+        assert torch.equal(a, b)                            # all-reduced gradient buckets are identical (SUM; 1/world in Adam)
+    assert r0["loss"][2] == 3
+
+
+def _single_vs_ddp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.parallel import comm
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    from tests.helpers import to_nhwc_padded
+    from tests.test_models_cpu import _zero_dropout
+    torch.set_num_threads(2)
+    comm.init_process_group(rank, world, torch.device("cpu"), timeout_s=120)
+    torch.manual_seed(5)
+    net, _ = get_model("basic", 10, device="cpu")
+    _zero_dropout(net)
+    dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "SGD", lr=1e-2))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 3, 28, 28, generator=g)
+    y = torch.randint(0, 10, (8,), generator=g)
+    dm.train_step(to_nhwc_padded(x[rank * 4:(rank + 1) * 4], torch.float32, "cpu"), y[rank * 4:(rank + 1) * 4])
+    if rank == 0:
+        torch.save(net.store.p.clone(), os.path.join(out_dir, "ddp.pt"))
+    comm.destroy_process_group()
+
+
+def test_ddp_equals_single_process_full_batch(tmp_path):
+    """Without BatchNorm, 2 ranks x batch 4 with gradient averaging == 1 process x batch 8 (the DDP contract)."""
+    mp.spawn(_single_vs_ddp_worker, nprocs=2, args=(2, _free_port(), str(tmp_path)), join=True)
+    sys.path.insert(0, ROOT)
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    from tests.helpers import to_nhwc_padded
+    from tests.test_models_cpu import _zero_dropout
+    torch.manual_seed(5)
+    net, _ = get_model("basic", 10, device="cpu")
+    _zero_dropout(net)
+    dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "SGD", lr=1e-2))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 3, 28, 28, generator=g)
+    y = torch.randint(0, 10, (8,), generator=g)
+    dm.train_step(to_nhwc_padded(x, torch.float32, "cpu"), y)
+    torch.testing.assert_close(net.store.p, torch.load(tmp_path / "ddp.pt"), rtol=1e-5, atol=1e-6)
+
+
+def _run_cli(tmp_path, args, env_extra, timeout=600):
+    env = dict(os.environ, DPA_MODEL_NAME="basic", DPA_GPUS="0,1", DPA_MASTER_PORT=str(_free_port()), DPA_NUM_THREADS="4",
+               PYTHONPATH=ROOT, **env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "main.py")] + args, cwd=tmp_path, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.fixture(scope="module")
+def tiny_data(tmp_path_factory):
+    sys.path.insert(0, ROOT)
+    from distributedpytorch_amd.data import mnist
+    root = str(tmp_path_factory.mktemp("cli_data"))
+    mnist.generate_synthetic_mnist(root, n_train=1000, n_test=200, seed=3)
+    return root
+
+
+def test_cli_train_resume_test_world2(tmp_path, tiny_data):
+    """python main.py train / train -f (resume) / test with 2 spawned gloo ranks; seeded rerun is bit-identical."""
+    r = _run_cli(tmp_path, ["train", "-d", tiny_data, "-e", "1", "-b", "50", "--debug"], {})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "world size: 2" in r.stdout and "Epoch: 001" in r.stdout and "model saved to" in r.stdout
+    ck0 = tmp_path / "rsl" / "checkpoint-mnist-basic-000.pt.tar"
+    assert ck0.exists() and (tmp_path / "rsl" / "bestmodel-mnist-basic.pt.tar").exists()
+    first = torch.load(ck0)
+    # seeded determinism: an identical second run writes an identical checkpoint
+    run2 = tmp_path / "again"
+    run2.mkdir()
+    r2 = _run_cli(run2, ["train", "-d", tiny_data, "-e", "1", "-b", "50", "--debug"], {})
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    second = torch.load(run2 / "rsl" / "checkpoint-mnist-basic-000.pt.tar")
+    for k, v in first["model_state_dict"].items():
+        assert torch.equal(v, second["model_state_dict"][k]), k
+    # resume: starts at epoch 2 and removes the stale per-epoch checkpoint (Q3, Q8)
+    r3 = _run_cli(tmp_path, ["train", "-d", tiny_data, "-e", "2", "-b", "50", "--debug", "-f", str(ck0)], {})
+    assert r3.returncode == 0, r3.stdout[-3000:] + r3.stderr[-3000:]
+    assert "epoch:0001: model loaded from" in r3.stdout and "Epoch: 002" in r3.stdout and "Epoch: 001" not in r3.stdout
+    assert (tmp_path / "rsl" / "checkpoint-mnist-basic-001.pt.tar").exists() and not ck0.exists()
+    # test sub-command
+    r4 = _run_cli(tmp_path, ["test", "-d", tiny_data, "-b", "100", "-f", str(tmp_path / "rsl" / "bestmodel-mnist-basic.pt.tar")], {})
+    assert r4.returncode == 0, r4.stdout[-3000:] + r4.stderr[-3000:]
+    assert "Acc:" in r4.stdout and "Time:" in r4.stdout
+
+
+def test_cli_fault_injection_tears_down_all_ranks(tmp_path, tiny_data):
+    """A rank that dies mid-training makes the launcher exit non-zero instead of hanging."""
+    r = _run_cli(tmp_path, ["train", "-d", tiny_data, "-e", "1", "-b", "50", "--debug"],
+                 {"DPA_FAULT_INJECT": "1:1", "DPA_COLLECTIVE_TIMEOUT_S": "30"}, timeout=300)
+    assert r.returncode != 0
+    assert "fault injection: rank 1" in r.stdout + r.stderr

@@ -8,45 +8,12 @@ from tests import torch_ref_models as ref
 from tests.helpers import framework_step, grads_by_name, oracle_step
 
 
-def _compare(name, oracle, hw, n=4, small_input=False, rtol=2e-3, atol=2e-4):
-    torch.manual_seed(0)
-    net, _ = get_model(name, 10, device="cpu", small_input=small_input)
-    sd = oracle.state_dict()
-    mine = net.state_dict(prefix="")
-    assert list(mine.keys()) == list(sd.keys())
-    for k in sd:
-        assert tuple(mine[k].shape) == tuple(sd[k].shape), k
-        assert mine[k].dtype == sd[k].dtype, k
-    net.load_state_dict(sd)
-    x = torch.randn(n, 3, hw, hw)
-    y = torch.randint(0, 10, (n,))
-    logits, loss, acc = framework_step(net, x, y)
-    ref_logits, ref_loss = oracle_step(oracle, x, y)
-    torch.testing.assert_close(logits, ref_logits, rtol=rtol, atol=atol)
-    assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
-    g = grads_by_name(net)
-    ref_g = {k: p.grad for k, p in oracle.named_parameters()}
-    for k, v in ref_g.items():
-        scale = max(v.abs().max().item(), 1e-6)
-        torch.testing.assert_close(g[k], v, rtol=5e-3, atol=5e-4 * scale, msg=lambda m, k=k: f"{k}: {m}")
-    # BN running statistics were updated like torch's
-    sd2 = oracle.state_dict()
-    mine2 = net.state_dict(prefix="")
-    for k in sd2:
-        if "running" in k or "num_batches" in k:
-            torch.testing.assert_close(mine2[k].float(), sd2[k].float(), rtol=1e-4, atol=1e-5)
-    # eval-mode forward uses the running statistics
-    logits_e, _, _ = framework_step(net, x, y, train=False)
-    ref_e, _ = oracle_step(oracle, x, y, train=False)
-    torch.testing.assert_close(logits_e, ref_e, rtol=rtol, atol=atol)
-
-
 def test_resnet18_parity_small():
-    _compare("resnet", ref.resnet18(10, small_input=True), 16, n=16, small_input=True)
+    _compare_zoo("resnet", ref.resnet18(10, small_input=True), 16, 16, small_input=True)
 
 
 def test_resnet18_parity_imagenet_stem():
-    _compare("resnet", ref.resnet18(10), 64, n=8)
+    _compare_zoo("resnet", ref.resnet18(10), 64, 8)
 
 
 def test_resnet50_parity():
@@ -57,7 +24,7 @@ def test_resnet50_parity():
         for k, v in oracle.named_parameters():
             if k.endswith("bn3.weight"):
                 v.fill_(0.2)
-    _compare("resnet50", oracle, 64, n=8)
+    _compare_zoo("resnet50", oracle, 64, 8)
 
 
 def _no_dropout(m):
@@ -87,10 +54,10 @@ def _zero_dropout(net):
     walk(net.net, set())
 
 
-def _compare_zoo(name, oracle, hw, n, gtol=2e-2):
+def _compare_zoo(name, oracle, hw, n, gtol=2e-2, small_input=False):
     """Parity with dropout disabled on both sides (masks come from different RNG streams by design)."""
     torch.manual_seed(0)
-    net, _ = get_model(name, 10, device="cpu")
+    net, _ = get_model(name, 10, device="cpu", small_input=small_input)
     _zero_dropout(net)
     _no_dropout(oracle)
     sd = oracle.state_dict()
@@ -113,6 +80,11 @@ def _compare_zoo(name, oracle, hw, n, gtol=2e-2):
         err = (g[k] - v).norm().item()
         # a conv bias followed by BatchNorm has an exactly-zero gradient: only absolute error is meaningful there
         assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax, (k, err, v.norm().item())
+    # BatchNorm running statistics were updated like torch's, and eval mode uses them
+    mine2 = net.state_dict(prefix="")
+    for k, v in oracle.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            torch.testing.assert_close(mine2[k].float(), v.float(), rtol=1e-4, atol=1e-5)
     logits_e, _, _ = framework_step(net, x, y, train=False)
     ref_e, _ = oracle_step(oracle, x.double(), y, train=False)
     torch.testing.assert_close(logits_e, ref_e.float(), rtol=2e-3, atol=2e-4)
