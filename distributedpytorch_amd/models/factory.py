@@ -67,6 +67,8 @@ def get_model(model_name, num_classes, feature_extract=False, use_pretrained=Fal
     if use_pretrained:
         raise RuntimeError("USE_PRETRAINED=True needs downloadable torchvision weights; load a checkpoint with -f instead")
     store = ParamStore(device, dtype)
+    from ..nn import layers as _layers
+    _layers._dropout_ids[0] = 0          # dropout stream ids are per model: two identical builds draw identical masks
     if model_name == "resnet":
         from .resnet import resnet18
         net = resnet18(store, num_classes, feature_extract, small_input)

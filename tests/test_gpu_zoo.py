@@ -1,0 +1,57 @@
+"""T3: every architecture of the zoo on the HIP kernels (fp32 exact-MFMA path) against fp64 torch oracles, plus a
+bf16 run of each for finiteness and loss agreement."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ZOO = [("alexnet", "AlexNet", 64, 4, 2e-2), ("vgg", "VGG11BN", 32, 8, 2e-2), ("squeezenet", "SqueezeNet10", 64, 4, 2e-2),
+       ("densenet", "DenseNet121", 64, 8, 3e-2), ("inception", "Inception3", 299, 4, 8e-2)]
+
+
+@pytest.mark.parametrize("name,cls,hw,n,gtol", ZOO)
+def test_zoo_gpu_fp32(name, cls, hw, n, gtol):
+    from distributedpytorch_amd.models.factory import get_model
+    from tests import torch_ref_models as ref
+    from tests.helpers import framework_step, grads_by_name, oracle_step
+    from tests.test_models_cpu import _no_dropout, _zero_dropout
+    torch.manual_seed(0)
+    oracle = _no_dropout(getattr(ref, cls)(10))
+    net, _ = get_model(name, 10, device="cuda", dtype=torch.float32)
+    _zero_dropout(net)
+    net.load_state_dict(oracle.state_dict())
+    x = torch.randn(n, 3, hw, hw)
+    y = torch.randint(0, 10, (n,))
+    logits, loss, acc = framework_step(net, x, y)
+    oracle = oracle.double()
+    ref_logits, ref_loss = oracle_step(oracle, x.double(), y)
+    torch.testing.assert_close(logits, ref_logits.float(), rtol=5e-3, atol=5e-4)
+    assert abs(loss - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
+    g = grads_by_name(net)
+    gmax = max(p.grad.norm().item() for p in oracle.parameters())
+    for k, p in oracle.named_parameters():
+        v = p.grad.float()
+        err = (g[k] - v).norm().item()
+        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax, (k, err, v.norm().item())
+    logits_e, _, _ = framework_step(net, x, y, train=False)
+    ref_e, _ = oracle_step(oracle, x.double(), y, train=False)
+    torch.testing.assert_close(logits_e, ref_e.float(), rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("name,cls,hw,n,gtol", ZOO)
+def test_zoo_gpu_bf16_runs(name, cls, hw, n, gtol):
+    from distributedpytorch_amd.models.factory import get_model
+    from tests import torch_ref_models as ref
+    from tests.helpers import framework_step, oracle_step
+    from tests.test_models_cpu import _no_dropout, _zero_dropout
+    torch.manual_seed(0)
+    oracle = _no_dropout(getattr(ref, cls)(10))
+    net, _ = get_model(name, 10, device="cuda", dtype=torch.bfloat16)
+    _zero_dropout(net)
+    net.load_state_dict(oracle.state_dict())
+    x = torch.randn(n, 3, hw, hw)
+    y = torch.randint(0, 10, (n,))
+    logits, loss, acc = framework_step(net, x, y)
+    _, ref_loss = oracle_step(oracle, x, y)
+    assert torch.isfinite(logits).all() and torch.isfinite(net.store.g).all()
+    assert abs(loss - ref_loss) < 0.08 * max(1.0, abs(ref_loss)), (loss, ref_loss)
