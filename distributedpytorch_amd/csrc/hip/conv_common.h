@@ -42,7 +42,14 @@ struct ConvParams {
   int Kg;            // R*S*sC
   int relu;          // apply max(.,0) in the epilogue
   int tilesM, tilesN;
-  FastDiv fd_dW, fd_dH, fd_sC, fd_S;
+  // dgrad "parity class" geometry: output pixels with (hi+ph) % sh == a, (wi+pw) % sw == b form a dense sub-problem
+  // that only sees taps r = a + sh*t, s = b + sw*t (stride-1 convs are the single class a = b = 0).
+  int cls_h0, cls_w0;      // first output pixel of the class along each dim
+  int cls_nh, cls_nw;      // pixels of the class along each dim  (fprop: dH, dW)
+  int base_y, base_x;      // source coordinate of class pixel 0 under tap 0 of the class
+  int tap_r0, tap_s0;      // first tap of the class
+  int nR, nS;              // taps of the class along each dim      (fprop: R, S)
+  FastDiv fd_nW, fd_nH, fd_sC, fd_nS;
 };
 
 template <typename T> struct MfmaT;

@@ -44,12 +44,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + row0 + 32 * i;
     if (m < p.M) {
-      const uint32_t t1 = fd_div((uint32_t)m, p.fd_dW);
-      const int xo = m - (int)t1 * p.dW;
-      const uint32_t img = fd_div(t1, p.fd_dH);
-      const int yo = (int)t1 - (int)img * p.dH;
+      const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+      const int xo = m - (int)t1 * p.cls_nw;
+      const uint32_t img = fd_div(t1, p.fd_nH);
+      const int yo = (int)t1 - (int)img * p.cls_nh;
       a_base[i] = img * (uint32_t)(p.sH * p.sW) ;
-      if (DGRAD) { a_y0[i] = yo + p.ph; a_x0[i] = xo + p.pw; }
+      if (DGRAD) { a_y0[i] = yo + p.base_y; a_x0[i] = xo + p.base_x; }
       else       { a_y0[i] = yo * p.sh - p.ph; a_x0[i] = xo * p.sw - p.pw; }
     } else {
       a_base[i] = 0xffffffffu; a_y0[i] = 0; a_x0[i] = 0;
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
     const int n = n0 + row0 + 32 * i;
-    b_base[i] = (n < p.dC) ? (uint32_t)n * (uint32_t)p.Kg : 0xffffffffu;
+    b_base[i] = (n < p.dC) ? (uint32_t)n * (uint32_t)(p.R * p.S * p.sC) : 0xffffffffu;
   }
 
   uint4 ra[A_PASSES], rb[B_PASSES];
@@ -68,19 +68,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const bool kin = kidx < p.Kg;
     const uint32_t tap = fd_div((uint32_t)kidx, p.fd_sC);
     const int c = kidx - (int)tap * p.sC;
-    const int r = (int)fd_div(tap, p.fd_S);
-    const int s = (int)tap - r * p.S;
+    const int r = (int)fd_div(tap, p.fd_nS);
+    const int s = (int)tap - r * p.nS;
+    // element offset of this chunk inside one filter row [R][S][sC]
+    const int woff = DGRAD ? (((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + c) : kidx;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      int sy, sx; bool ok = kin && (a_base[i] != 0xffffffffu);
-      if (DGRAD) {
-        const int ty = a_y0[i] - r, tx = a_x0[i] - s;
-        if (p.sh == 1 && p.sw == 1) { sy = ty; sx = tx; }
-        else {
-          sy = ty / p.sh; sx = tx / p.sw;   // ty,tx may be negative: checked below before use
-          ok = ok && (ty >= 0) && (tx >= 0) && (sy * p.sh == ty) && (sx * p.sw == tx);
-        }
-      } else { sy = a_y0[i] + r; sx = a_x0[i] + s; }
+      bool ok = kin && (a_base[i] != 0xffffffffu);
+      const int sy = DGRAD ? a_y0[i] - r : a_y0[i] + r;
+      const int sx = DGRAD ? a_x0[i] - s : a_x0[i] + s;
       ok = ok && ((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (ok) {
@@ -92,7 +88,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (kin && b_base[i] != 0xffffffffu) v = *reinterpret_cast<const uint4*>(wgt + (size_t)b_base[i] + kidx);
+      if (kin && b_base[i] != 0xffffffffu) v = *reinterpret_cast<const uint4*>(wgt + (size_t)b_base[i] + woff);
       rb[i] = v;
     }
   };
@@ -183,7 +179,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
       }
       if (m < p.M && col < p.dC) {
-        const size_t off = (size_t)m * (size_t)p.d_cs + (size_t)(p.d_co + col);
+        size_t pixel = (size_t)m;
+        if (DGRAD && (p.sh != 1 || p.sw != 1)) {      // class row -> (img, hi, wi) of the full gradient tensor
+          const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+          const int jx = m - (int)t1 * p.cls_nw;
+          const uint32_t img = fd_div(t1, p.fd_nH);
+          const int iy = (int)t1 - (int)img * p.cls_nh;
+          pixel = ((size_t)img * p.dH + (size_t)(p.cls_h0 + p.sh * iy)) * p.dW + (size_t)(p.cls_w0 + p.sw * jx);
+        }
+        const size_t off = pixel * (size_t)p.d_cs + (size_t)(p.d_co + col);
         if (addend) {
           Vec16<T> av; av.load(addend + off);
 #pragma unroll
@@ -251,14 +255,9 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
 }
 
 template <typename T>
-static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
-  p.M = p.sN * p.dH * p.dW;
-  p.Kg = p.R * p.S * p.sC;
-  constexpr int VEC = 16 / sizeof(T);
-  if (p.sC % VEC || p.s_cs % VEC || p.s_co % VEC || p.dC % VEC || p.d_cs % VEC || p.d_co % VEC) return 1;
-  if ((size_t)p.sN * p.sH * p.sW >= 0x7fffffffull || (size_t)p.M >= 0x7fffffffull) return 2;
-  p.fd_dW = make_fastdiv(p.dW); p.fd_dH = make_fastdiv(p.dH);
-  p.fd_sC = make_fastdiv(p.sC); p.fd_S = make_fastdiv(p.S);
+static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
+  p.fd_nW = make_fastdiv(p.cls_nw > 0 ? p.cls_nw : 1); p.fd_nH = make_fastdiv(p.cls_nh > 0 ? p.cls_nh : 1);
+  p.fd_sC = make_fastdiv(p.sC); p.fd_nS = make_fastdiv(p.nS > 0 ? p.nS : 1);
   // tile selection: narrow outputs get a tall tile; small problems get small tiles so that the grid
   // still covers the 256 CUs.
   const long long big_tiles = (long long)((p.M + 127) / 128) * ((p.dC + 127) / 128);
@@ -268,6 +267,39 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
     else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
   } else if (big_tiles >= 384)        launch_cfg<T, 2, 2, 4, 4>(p, dgrad, s);   // 128 x 128
   else                                launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
+}
+
+template <typename T>
+static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (p.sC % VEC || p.s_cs % VEC || p.s_co % VEC || p.dC % VEC || p.d_cs % VEC || p.d_co % VEC) return 1;
+  if ((size_t)p.sN * p.sH * p.sW >= 0x7fffffffull || (size_t)p.sN * p.dH * p.dW >= 0x7fffffffull) return 2;
+  if (!dgrad) {
+    p.cls_h0 = p.cls_w0 = 0; p.cls_nh = p.dH; p.cls_nw = p.dW;
+    p.base_y = p.base_x = 0; p.tap_r0 = p.tap_s0 = 0; p.nR = p.R; p.nS = p.S;
+    p.M = p.sN * p.dH * p.dW;
+    p.Kg = p.R * p.S * p.sC;
+    launch_tiles<T>(p, 0, s);
+    return 0;
+  }
+  // dgrad: one dense sub-problem per (a, b) parity class; a stride-s conv costs 1x the fprop work instead of s^2 x
+  for (int a = 0; a < p.sh; ++a)
+    for (int b = 0; b < p.sw; ++b) {
+      ConvParams q = p;
+      q.cls_h0 = ((a - p.ph) % p.sh + p.sh) % p.sh;
+      q.cls_w0 = ((b - p.pw) % p.sw + p.sw) % p.sw;
+      q.cls_nh = q.cls_h0 < p.dH ? (p.dH - q.cls_h0 + p.sh - 1) / p.sh : 0;
+      q.cls_nw = q.cls_w0 < p.dW ? (p.dW - q.cls_w0 + p.sw - 1) / p.sw : 0;
+      if (q.cls_nh == 0 || q.cls_nw == 0) continue;
+      q.tap_r0 = a; q.tap_s0 = b;
+      q.nR = a < p.R ? (p.R - a + p.sh - 1) / p.sh : 0;
+      q.nS = b < p.S ? (p.S - b + p.sw - 1) / p.sw : 0;
+      q.base_y = (q.cls_h0 + p.ph - a) / p.sh;
+      q.base_x = (q.cls_w0 + p.pw - b) / p.sw;
+      q.M = p.sN * q.cls_nh * q.cls_nw;
+      q.Kg = q.nR * q.nS * p.sC;          // 0 taps: the kernel only runs its epilogue (zeros + addend)
+      launch_tiles<T>(q, 1, s);
+    }
   return 0;
 }
 

@@ -29,22 +29,25 @@ template <typename T> struct WgLds;
 template <> struct WgLds<bf16_t> { static constexpr int PAD = 32; };   // bytes; shifts each pixel row by 8 banks
 template <> struct WgLds<float>  { static constexpr int PAD = 64; };   // (pitch/4) % 32 == 16
 
-template <typename T, int TM, int TN>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams p) {
-  constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BKP = 8 * VEC;                          // pixels per K-tile (64 bf16 / 32 fp32)
   constexpr int PITCH_A = BM * sizeof(T) + WgLds<T>::PAD;
   constexpr int PITCH_B = BN * sizeof(T) + WgLds<T>::PAD;
   constexpr int CPR_A = BM / VEC, CPR_B = BN / VEC;     // 16-byte chunks per pixel row
-  constexpr int A_PASSES = BKP * CPR_A / 256, B_PASSES = BKP * CPR_B / 256;
-  constexpr int RPP_A = 256 / CPR_A, RPP_B = 256 / CPR_B;   // pixel rows per pass
+  constexpr int A_PASSES = BKP * CPR_A / 256;
+  constexpr int RPP_A = 256 / CPR_A;                    // pixel rows per pass (A)
+  constexpr int TPR = 256 / BKP;                        // threads per pixel row (B): 4 bf16 / 8 fp32
+  constexpr int B_CHUNKS = CPR_B / TPR;                 // chunks of ONE pixel row staged by a thread
+  static_assert(WM * WN == 4, "4 waves per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;
   char* ldsB = smem + BKP * PITCH_A;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int bid = blockIdx.x;
   const int tilesMN = p.tilesM * p.tilesN;
   const int z = bid / tilesMN;
@@ -57,20 +60,31 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams p) {
   const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
 
-  // A operand (dy): this thread stages chunk ca of pixel rows ra0 + RPP_A*i
+  // A operand (dy, dense [pixel][cout]): this thread stages chunk ca of pixel rows ra0 + RPP_A*i
   const int ca = tid % CPR_A, ra0 = tid / CPR_A;
   const int a_col = m0 + ca * VEC;
   const bool a_ok = a_col < p.K;
-  // B operand (x gathered): chunk cb -> fixed (r, s, c) for the whole reduction
-  const int cb = tid % CPR_B, rb0 = tid / CPR_B;
-  const int nidx = n0 + cb * VEC;
-  const bool b_ok = nidx < p.Ng;
-  const uint32_t tap = fd_div((uint32_t)(b_ok ? nidx : 0), p.fd_C);
-  const int bc = (b_ok ? nidx : 0) - (int)tap * p.C;
-  const int br = (int)fd_div(tap, p.fd_S);
-  const int bs = (int)tap - br * p.S;
+  // B operand (x gathered): a thread owns ONE pixel row of the tile and B_CHUNKS channel chunks of it, so the
+  // (img, ho, wo) decomposition is done once per thread per K-step; every chunk has a fixed tap (r, s, c) whose
+  // address delta is precomputed (the first version decomposed the pixel once per chunk and was VALU bound).
+  const int brow = tid / TPR, bsub = tid % TPR;
+  int b_dr[B_CHUNKS], b_ds[B_CHUNKS], b_delta[B_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < B_CHUNKS; ++i) {
+    const int nidx = n0 + (bsub + TPR * i) * VEC;
+    if (nidx < p.Ng) {
+      const uint32_t tap = fd_div((uint32_t)nidx, p.fd_C);
+      const int c = nidx - (int)tap * p.C;
+      const int r = (int)fd_div(tap, p.fd_S);
+      const int s = (int)tap - r * p.S;
+      b_dr[i] = r; b_ds[i] = s;
+      b_delta[i] = (r * p.W + s) * p.c_cs + p.c_co + c;
+    } else {
+      b_dr[i] = -0x40000000; b_ds[i] = 0; b_delta[i] = 0;     // fails the bounds check below -> zeros
+    }
+  }
 
-  uint4 ra[A_PASSES], rb[B_PASSES];
+  uint4 ra[A_PASSES], rb[B_CHUNKS];
   auto load_tile = [&](int pix0) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
@@ -79,21 +93,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams p) {
       if (a_ok && pix < pix_end) v = *reinterpret_cast<const uint4*>(dy + (size_t)pix * p.k_cs + p.k_co + a_col);
       ra[i] = v;
     }
+    const int pix = pix0 + brow;
+    const bool pin = pix < pix_end;
+    const uint32_t t1 = fd_div((uint32_t)(pin ? pix : 0), p.fd_Wo);
+    const int wo = (pin ? pix : 0) - (int)t1 * p.Wo;
+    const uint32_t img = fd_div(t1, p.fd_Ho);
+    const int ho = (int)t1 - (int)img * p.Ho;
+    const int h0 = ho * p.sh - p.ph, w0 = wo * p.sw - p.pw;
+    const T* base = x + ((size_t)img * (p.H * p.W) + (ptrdiff_t)(h0 * p.W + w0)) * p.c_cs;
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int pix = pix0 + rb0 + RPP_B * i;
+    for (int i = 0; i < B_CHUNKS; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (b_ok && pix < pix_end) {
-        const uint32_t t1 = fd_div((uint32_t)pix, p.fd_Wo);
-        const int wo = pix - (int)t1 * p.Wo;
-        const uint32_t img = fd_div(t1, p.fd_Ho);
-        const int ho = (int)t1 - (int)img * p.Ho;
-        const int hi = ho * p.sh - p.ph + br, wi = wo * p.sw - p.pw + bs;
-        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-          const size_t off = ((size_t)img * (p.H * p.W) + (size_t)(hi * p.W + wi)) * p.c_cs + p.c_co + bc;
-          v = *reinterpret_cast<const uint4*>(x + off);
-        }
-      }
+      if (pin && (unsigned)(h0 + b_dr[i]) < (unsigned)p.H && (unsigned)(w0 + b_ds[i]) < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4*>(base + b_delta[i]);
       rb[i] = v;
     }
   };
@@ -102,8 +114,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < A_PASSES; ++i)
       *reinterpret_cast<uint4*>(ldsA + (ra0 + RPP_A * i) * PITCH_A + ca * 16) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i)
-      *reinterpret_cast<uint4*>(ldsB + (rb0 + RPP_B * i) * PITCH_B + cb * 16) = rb[i];
+    for (int i = 0; i < B_CHUNKS; ++i)
+      *reinterpret_cast<uint4*>(ldsB + brow * PITCH_B + (bsub + TPR * i) * 16) = rb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -194,17 +206,26 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-// Sum the split-K slabs in a fixed order (deterministic) into the gradient arena.
+// Sum the split-K slabs in a fixed order (deterministic) into the gradient arena.  A block owns 64 float4 columns and
+// splits the slabs over 4 lanes of z (then a fixed-order LDS combine), so small filters with many slabs still fill the chip.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            long long n, int splitK, int accumulate) {
-  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const long long stride = (long long)gridDim.x * blockDim.x * 4;
-  for (; i < n; i += stride) {   // n is a multiple of 4 (channel counts are multiples of 4)
-    float4 s = *reinterpret_cast<const float4*>(slabs + i);
-    for (int z = 1; z < splitK; ++z) {
+  __shared__ float4 red[4][64];
+  const int col = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const long long i = ((long long)blockIdx.x * 64 + col) * 4;      // n is a multiple of 4
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+#pragma unroll 4
+    for (int z = zl; z < splitK; z += 4) {
       const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
+  }
+  red[zl][col] = s;
+  __syncthreads();
+  if (zl == 0 && i < n) {
+#pragma unroll
+    for (int l = 1; l < 4; ++l) { const float4 t = red[l][col]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
     if (accumulate) {
       const float4 o = *reinterpret_cast<const float4*>(out + i);
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
@@ -213,15 +234,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <typename T, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN>
 static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t s) {
-  constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16, VEC = 16 / sizeof(T), BKP = 8 * VEC;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, VEC = 16 / sizeof(T), BKP = 8 * VEC;
   p.tilesM = (p.K + BM - 1) / BM;
   p.tilesN = (p.Ng + BN - 1) / BN;
   const int tiles = p.tilesM * p.tilesN;
   const int ksteps = (p.P + BKP - 1) / BKP;
-  int split = (1024 + tiles - 1) / tiles;
-  if (split > ksteps / 4) split = ksteps / 4;
+  int split = (512 + tiles - 1) / tiles;          // ~2 blocks per CU; slab traffic grows with the split
+  if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
   if (!workspace) split = 1;
   int steps_per = (ksteps + split - 1) / split;
@@ -230,10 +251,10 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   p.pixPerSplit = steps_per * BKP;
   p.out = split == 1 ? grad : workspace;
   size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
   if (split > 1) {
     const long long n = (long long)p.K * p.Ng;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dpa_grid((n + 3) / 4, 256)), dim3(256), 0, s, workspace, grad, n,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, workspace, grad, n,
                        split, p.accumulate);
   }
 }
@@ -247,8 +268,11 @@ static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_
   if ((size_t)p.N * p.H * p.W >= 0x7fffffffull || (size_t)p.P >= 0x7fffffffull) return 2;
   p.fd_Wo = make_fastdiv(p.Wo); p.fd_Ho = make_fastdiv(p.Ho);
   p.fd_C = make_fastdiv(p.C); p.fd_S = make_fastdiv(p.S);
-  if (p.K <= 64 || p.Ng <= 64) wg_launch<T, 2, 2>(p, grad, workspace, s);
-  else                         wg_launch<T, 4, 4>(p, grad, workspace, s);
+  if (p.Ng <= 64)      wg_launch<T, 2, 2, 2, 2>(p, grad, workspace, s);   //  64 x  64
+  else if (p.K <= 64 && p.Ng % 192 == 0 && p.Ng % 256 != 0)
+                       wg_launch<T, 1, 4, 4, 3>(p, grad, workspace, s);   //  64 x 192: 3x3 x 64 channels without padding
+  else if (p.K <= 64)  wg_launch<T, 1, 4, 4, 4>(p, grad, workspace, s);   //  64 x 256: narrow Cout, all waves share the dy tile
+  else                 wg_launch<T, 2, 2, 4, 4>(p, grad, workspace, s);   // 128 x 128
   return 0;
 }
 
@@ -259,9 +283,10 @@ DPA_API int dpa_conv_wgrad(WgradParams* p, float* grad, float* workspace, int dt
 }
 // upper bound on workspace floats for a layer: split <= 1024 tiles-worth, i.e. <= ~1024*BM*BN + K*Ng
 DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {
-  const int bm = (K <= 64 || Ng <= 64) ? 64 : 128;
-  const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bm - 1) / bm);
-  long long split = (1024 + tiles - 1) / tiles;
+  const int bm = (Ng <= 64 || K <= 64) ? 64 : 128;
+  const int bn = Ng <= 64 ? 64 : (K <= 64 ? ((Ng % 192 == 0 && Ng % 256 != 0) ? 192 : 256) : 128);
+  const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bn - 1) / bn);
+  long long split = (512 + tiles - 1) / tiles;
   return split * (long long)K * Ng;
 }
 DPA_API int dpa_wgrad_params_size() { return (int)sizeof(WgradParams); }
