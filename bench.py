@@ -53,8 +53,10 @@ def main():
     from distributedpytorch_amd.parallel import comm
     from distributedpytorch_amd.parallel.ddp import DistributedModel
 
-    if world > 1:
+    force = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1"     # 1-GPU rehearsal of the RCCL path
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         comm.init_process_group(rank, world, device)
 
     torch.manual_seed(1234)
@@ -112,7 +114,7 @@ def main():
                        "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "hipgraph": use_graph,
                        "mean_loss": round(loss, 4)},
         }), flush=True)
-    if world > 1:
+    if world > 1 or force:
         comm.destroy_process_group()
     return 0
 

@@ -4,6 +4,7 @@ the host runtime.  Outputs land next to the package so they travel with the sour
   distributedpytorch_amd/lib/libdpamd_hip.so   HIP/CDNA4 kernels (C ABI, loaded with ctypes)
   distributedpytorch_amd/lib/libdpamd_host.so  C++ host runtime (sampler, IDX reader, bucket planner,
                                                TCP rendezvous store) - no HIP dependency
+  distributedpytorch_amd/lib/libdpamd_comm.so  C++ RCCL communicator (own HIP comm stream + event fencing)
 
 Usage: python -m distributedpytorch_amd.csrc.build [--force] [--jobs N]
 """
@@ -59,9 +60,10 @@ def build(force=False, jobs=None, verbose=True):
     hip_hdr = _sources("hip", (".h",))
     host_src = _sources("host", (".cpp",))
     host_hdr = _sources("host", (".h",))
+    comm_src = _sources("comm", (".cpp",))
     tasks = []
-    objs = {"hip": [], "host": []}
-    for kind, srcs, hdrs in (("hip", hip_src, hip_hdr), ("host", host_src, host_hdr)):
+    objs = {"hip": [], "host": [], "comm": []}
+    for kind, srcs, hdrs in (("hip", hip_src, hip_hdr), ("host", host_src, host_hdr), ("comm", comm_src, [])):
         for src in srcs:
             base = os.path.splitext(os.path.basename(src))[0]
             obj = os.path.join(OBJDIR, f"{kind}_{base}.o")
@@ -72,6 +74,8 @@ def build(force=False, jobs=None, verbose=True):
                 continue
             if kind == "hip":
                 cmd = [HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj]
+            elif kind == "comm":
+                cmd = ["g++"] + HOST_FLAGS + ["-D__HIP_PLATFORM_AMD__", f"-I{ROCM}/include", "-c", src, "-o", obj]
             else:
                 cmd = ["g++"] + HOST_FLAGS + ["-c", src, "-o", obj]
             tasks.append((cmd, src, obj, stamp, digest))
@@ -97,6 +101,13 @@ def build(force=False, jobs=None, verbose=True):
         subprocess.run(cmd, check=True)
         if verbose:
             print(f"[build] linked {os.path.relpath(host_so, PKG)}", flush=True)
+    comm_so = os.path.join(LIBDIR, "libdpamd_comm.so")
+    if objs["comm"] and (relink or not os.path.exists(comm_so)):
+        # like the kernel library: no rpath, so librccl.so.1 / libamdhip64.so.7 bind to the copies torch has loaded
+        cmd = ["g++", "-shared", "-fPIC", "-o", comm_so] + objs["comm"] + [f"-L{ROCM}/lib", "-lrccl", "-lamdhip64"]
+        subprocess.run(cmd, check=True)
+        if verbose:
+            print(f"[build] linked {os.path.relpath(comm_so, PKG)}", flush=True)
     return hip_so, host_so
 
 

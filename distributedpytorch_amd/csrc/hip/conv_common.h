@@ -41,6 +41,7 @@ struct ConvParams {
   int M;             // sN*dH*dW
   int Kg;            // R*S*sC
   int relu;          // apply max(.,0) in the epilogue
+  int no_uni;        // debug / A-B switch: force the general address path (DPA_CONV_UNI=0)
   int tilesM, tilesN;
   // dgrad "parity class" geometry: output pixels with (hi+ph) % sh == a, (wi+pw) % sw == b form a dense sub-problem
   // that only sees taps r = a + sh*t, s = b + sw*t (stride-1 convs are the single class a = b = 0).

@@ -14,8 +14,12 @@
 //   tile is staged through LDS so global stores are 16 B per lane along the channel dimension, at an
 //   arbitrary channel offset/stride of the destination buffer (zero-copy concat).
 #include "conv_common.h"
+#include <cstdlib>
 
-template <typename T, int WM, int WN, int TM, int TN, bool DGRAD>
+// 64 zero bytes: the source of every padded / out-of-range 16-byte chunk of the LDS-DMA staging path
+__device__ uint4 dpa_zero_chunk[4];
+
+template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
@@ -23,6 +27,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
   static_assert(WM * WN == 4, "4 waves per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE_BYTES = (BM + BN) * 128;      // one K-tile of both operands
   char* ldsA = smem;
   char* ldsB = smem + BM * 128;
 
@@ -36,8 +41,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
 
   // ---- per-thread gather state: this thread stages chunk `ck` of rows (tid>>3) + 32*i -----------------
-  const int ck = tid & 7;
+  // Register staging: the thread owns logical chunk tid&7 and writes it to the swizzled slot.  LDS-DMA staging
+  // (global_load_lds writes wave-base + lane*16, no per-lane scatter): the thread owns the physical slot tid&7 and
+  // fetches the logical chunk that the swizzle maps there; (row>>1)&7 == ((wave&1)<<2 | lane>>4) for every pass
+  // because rows advance by 32 per pass, so the chunk -> tap decomposition is still per-thread constant.
   const int row0 = tid >> 3;
+  const int ck = GLDS ? ((tid & 7) ^ ((row0 >> 1) & 7)) : (tid & 7);
   uint32_t a_base[A_PASSES];   // element offset of (img, 0, 0, s_co) in src; 0xffffffff when the row is out of range
   int a_y0[A_PASSES], a_x0[A_PASSES];
 #pragma unroll
@@ -62,8 +71,54 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     b_base[i] = (n < p.dC) ? (uint32_t)n * (uint32_t)(p.R * p.S * p.sC) : 0xffffffffu;
   }
 
-  uint4 ra[A_PASSES], rb[B_PASSES];
-  auto load_tile = [&](int kt) {
+  // ---- uniform-tap fast path --------------------------------------------------------------------------------
+  // When the channel count is a multiple of the K-tile (every ResNet/VGG/DenseNet/Inception layer but the stem) all
+  // chunks of a K-tile belong to ONE filter tap, so (r, s) and the tap's address delta are wave-uniform (scalar
+  // ALU) and the per-row validity of each tap is a precomputed bit mask: per pass the address generation is a bit
+  // test, one 64-bit add and a select instead of two magic divisions, bounds compares and a multiply (the first
+  // version spent 4.9 VALU instructions per MFMA here, profiles/README.md).
+  const int ntaps = p.nR * p.nS;
+  // (a dgrad parity class without taps has Kg == 0: it must take the general path, whose loads are all predicated off)
+  const bool uni = (p.sC % BKE == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni;
+  long long a_rowoff[A_PASSES];
+  uint32_t a_mask[A_PASSES];
+  if (uni) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      a_rowoff[i] = ((long long)a_base[i] + (long long)a_y0[i] * p.sW + a_x0[i]) * p.s_cs + p.s_co + ck * VEC;
+      uint32_t mk = 0;
+      if (a_base[i] != 0xffffffffu) {
+        for (int t = 0; t < ntaps; ++t) {
+          const int r = (int)fd_div((uint32_t)t, p.fd_nS), sx_ = t - r * p.nS;
+          const int sy = DGRAD ? a_y0[i] - r : a_y0[i] + r;
+          const int sx = DGRAD ? a_x0[i] - sx_ : a_x0[i] + sx_;
+          if (((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW)) mk |= 1u << t;
+        }
+      }
+      a_mask[i] = mk;
+    }
+  }
+  const T* const zero = reinterpret_cast<const T*>(dpa_zero_chunk);
+
+  // Source pointer of every chunk this thread stages for K-tile kt (the zero chunk for padding / out of range).
+  const T* pa[A_PASSES];
+  const T* pb[B_PASSES];
+  auto gen_addresses = [&](int kt) __attribute__((always_inline)) {
+    if (uni) {
+      const uint32_t k0 = (uint32_t)kt * BKE;                       // wave-uniform from here on
+      const uint32_t tap = fd_div(k0, p.fd_sC);
+      const int cbase = (int)(k0 - tap * (uint32_t)p.sC);
+      const int r = (int)fd_div(tap, p.fd_nS);
+      const int s = (int)tap - r * p.nS;
+      const long long delta = (long long)(DGRAD ? -(r * p.sW + s) : (r * p.sW + s)) * p.s_cs + cbase;
+      const int woff = (DGRAD ? (((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + cbase) : (int)k0) + ck * VEC;
+      const uint32_t bit = 1u << tap;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) pa[i] = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i)   // rows beyond dC alias row 0: their output columns are never stored
+        pb[i] = wgt + (size_t)(b_base[i] == 0xffffffffu ? 0u : b_base[i]) + woff;
+    } else {
     const int kidx = kt * BKE + ck * VEC;
     const bool kin = kidx < p.Kg;
     const uint32_t tap = fd_div((uint32_t)kidx, p.fd_sC);
@@ -78,25 +133,43 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
       const int sy = DGRAD ? a_y0[i] - r : a_y0[i] + r;
       const int sx = DGRAD ? a_x0[i] - s : a_x0[i] + s;
       ok = ok && ((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const size_t off = ((size_t)a_base[i] + (size_t)(sy * p.sW + sx)) * (size_t)p.s_cs + (size_t)(p.s_co + c);
-        v = *reinterpret_cast<const uint4*>(src + off);
-      }
-      ra[i] = v;
+      const size_t off = ((size_t)a_base[i] + (size_t)(sy * p.sW + sx)) * (size_t)p.s_cs + (size_t)(p.s_co + c);
+      pa[i] = ok ? src + off : zero;
     }
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kin && b_base[i] != 0xffffffffu) v = *reinterpret_cast<const uint4*>(wgt + (size_t)b_base[i] + woff);
-      rb[i] = v;
+    for (int i = 0; i < B_PASSES; ++i)
+      pb[i] = (kin && b_base[i] != 0xffffffffu) ? wgt + (size_t)b_base[i] + woff : zero;
     }
   };
-  auto store_tile = [&]() {
+
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers
+  u32x4 ra[A_PASSES], rb[B_PASSES];
+  auto load_tile = [&]() __attribute__((always_inline)) {     // after gen_addresses(kt)
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<uint4*>(ldsA + lds_off(row0 + 32 * i, ck)) = ra[i];
+    for (int i = 0; i < A_PASSES; ++i) ra[i] = *reinterpret_cast<const u32x4*>(pa[i]);
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) *reinterpret_cast<uint4*>(ldsB + lds_off(row0 + 32 * i, ck)) = rb[i];
+    for (int i = 0; i < B_PASSES; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pb[i]);
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<u32x4*>(ldsA + lds_off(row0 + 32 * i, ck)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) *reinterpret_cast<u32x4*>(ldsB + lds_off(row0 + 32 * i, ck)) = rb[i];
+  };
+
+  // LDS-DMA staging of K-tile kt into stage buffer `buf`: one global_load_lds_dwordx4 per 8 rows x 128 B per wave
+  // (the destination is wave-base + lane*16, so the swizzle lives in the per-lane SOURCE chunk, see `ck`).
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_tile = [&](int buf) __attribute__((always_inline)) {     // after gen_addresses(kt)
+    char* stage = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void*)pa[i], (lds_void*)(stage + (i * 32 + wave_u * 8) * 128), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void*)pb[i], (lds_void*)(stage + BM * 128 + (i * 32 + wave_u * 8) * 128), 16, 0, 0);
   };
 
   f32x4 acc[TM][TN];
@@ -107,29 +180,49 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
   const int nkt = (p.Kg + BKE - 1) / BKE;
   const int fr = lane & 15, fq = lane >> 4;
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  auto compute_tile = [&](const char* tA, const char* tB) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const uint4*>(ldsA + lds_off(wm * TM * 16 + i * 16 + fr, ks * 4 + fq));
+        fa[i] = *reinterpret_cast<const uint4*>(tA + lds_off(wm * TM * 16 + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const uint4*>(ldsB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
+        fb[j] = *reinterpret_cast<const uint4*>(tB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) MfmaT<T>::mma(fa[i], fb[j], acc[i][j]);
     }
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      store_tile();
+  };
+  if constexpr (GLDS) {
+    // two stage buffers, ONE barrier per K-tile: [wait for tile kt + everyone done with tile kt-1] -> issue tile kt+1
+    // into the buffer tile kt-1 used -> MFMAs on tile kt while the DMA of kt+1 is in flight.
+    gen_addresses(0);
+    issue_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (kt + 1 < nkt) { gen_addresses(kt + 1); issue_tile((kt + 1) & 1); }
+      const char* st = smem + (kt & 1) * STAGE_BYTES;
+      compute_tile(st, st + BM * 128);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    gen_addresses(0);
+    load_tile();
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) { gen_addresses(kt + 1); load_tile(); }
+      compute_tile(ldsA, ldsB);
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        store_tile();
+        __syncthreads();
+      }
     }
   }
 
@@ -246,12 +339,25 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   p.tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.dC + BN - 1) / BN;
-  size_t lds = (size_t)(BM + BN) * 128;
+  // staging policy: LDS-DMA + 2 stage buffers pays when there are enough K-tiles to pipeline; short reductions
+  // (1x1 convs on few channels) run more blocks per CU with the single-buffer register-staged variant.
+  static const int no_uni = [] { const char* e = getenv("DPA_CONV_UNI"); return (e && e[0] == '0') ? 1 : 0; }();
+  p.no_uni = no_uni;
+  static const int policy = [] { const char* e = getenv("DPA_CONV_STAGING"); return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'g' ? 2 : 0)); }();
+  constexpr int BKE = 8 * (16 / (int)sizeof(T));
+  const int nkt = (p.Kg + BKE - 1) / BKE;
+  const bool use_glds = policy == 2 || (policy == 0 && nkt >= 8);
+  size_t lds = (size_t)(BM + BN) * 128 * (use_glds ? 2 : 1);
   size_t epi = (size_t)(4 * 16 * (TN * 16 + 4) + WM * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   dim3 grid(p.tilesM * p.tilesN), block(256);
-  if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true>), grid, block, lds, s, p);
-  else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false>), grid, block, lds, s, p);
+  if (use_glds) {     // LDS-DMA staging, double-buffered (default)
+    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
+    else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true>), grid, block, lds, s, p);
+  } else {            // register staging, single buffer (DPA_CONV_STAGING=reg: A/B reference)
+    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false>), grid, block, lds, s, p);
+    else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false>), grid, block, lds, s, p);
+  }
 }
 
 template <typename T>

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
   }
 
   uint4 ra[A_PASSES], rb[B_CHUNKS];
-  auto load_tile = [&](int pix0) {
+  auto load_tile = [&](int pix0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int pix = pix0 + ra0 + RPP_A * i;
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
       rb[i] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
       *reinterpret_cast<uint4*>(ldsA + (ra0 + RPP_A * i) * PITCH_A + ca * 16) = ra[i];

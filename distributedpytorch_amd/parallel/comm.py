@@ -12,6 +12,16 @@ import torch
 import torch.distributed as dist
 
 
+def warm_kernel_library(device):
+    """Load the gfx950 code object (one trivial launch + sync) before any RCCL communicator exists: on the ROCm 7.0
+    runtime a module first loaded AFTER ncclCommInitRank deadlocked later cross-stream event waits (measured with the
+    native communicator, scripts/dbg_rccl5.py vs dbg_rccl6.py); loading it first costs ~ms once."""
+    from .. import ops
+    warm = torch.zeros(2, dtype=torch.int64, device=device)
+    ops.rng_advance(warm)
+    torch.cuda.synchronize(device)
+
+
 def init_process_group(rank, world_size, device, timeout_s=600.0, master_addr=None, master_port=None):
     """Initialise torch.distributed for this rank.  device: torch.device('cuda', i) or cpu."""
     if master_addr:
@@ -20,6 +30,8 @@ def init_process_group(rank, world_size, device, timeout_s=600.0, master_addr=No
         os.environ["MASTER_PORT"] = str(master_port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver stack
     backend = "nccl" if device.type == "cuda" else "gloo"
+    if device.type == "cuda":
+        warm_kernel_library(device)
     kwargs = dict(backend=backend, init_method="env://", world_size=world_size, rank=rank,
                   timeout=datetime.timedelta(seconds=timeout_s))
     if device.type == "cuda":

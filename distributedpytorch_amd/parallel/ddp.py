@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 
 from ..nn.engine import Tape
+from ..utils.trace import PhaseTimer, rng
 from ..nn.loss import Criterion
 from ..nn.optim import ArenaOptimizer
 from .reducer import GradReducer
@@ -20,14 +21,14 @@ class DistributedModel:
     """The DDP-wrapped model + optimizer: owns the reducer and the device-side metric accumulators."""
 
     def __init__(self, net, criterion: Criterion, optimizer: ArenaOptimizer = None, first_bucket_mb=1.0,
-                 bucket_cap_mb=25.0, broadcast_buffers=True, sync_comm=False):
+                 bucket_cap_mb=25.0, broadcast_buffers=True, sync_comm=False, native_comm=None):
         self.net, self.criterion, self.opt = net, criterion, optimizer
         dev = net.store.device
         self.device = dev
         self.reducer = None
         if optimizer is not None:
             self.reducer = GradReducer(net.store, optimizer, first_bucket_mb, bucket_cap_mb, broadcast_buffers,
-                                       sync_mode=sync_comm)
+                                       sync_mode=sync_comm, native_comm=native_comm)
         self.metrics = torch.zeros(2, device=dev)          # last-iteration (loss, acc)
         self.accum = torch.zeros(3, device=dev)            # epoch sums: loss, acc, iterations
         self._graph = None
@@ -48,15 +49,39 @@ class DistributedModel:
         """x: NHWC compute-dtype batch on the device; labels: int64 on the device."""
         net, red = self.net, self.reducer
         net.train()
-        red.sync_buffers()
+        with rng("sync_buffers"):
+            red.sync_buffers()
         tape = Tape()
         tape.param_ready_hook = red.param_ready
         red.begin_backward()
-        self._forward_loss(x, labels, tape)
-        tape.backward()
-        red.finish_and_step()
+        with rng("forward+loss"):
+            self._forward_loss(x, labels, tape)
+        with rng("backward+allreduce"):
+            tape.backward()
+        with rng("wait+optimizer"):
+            red.finish_and_step()
         from .. import ops
         ops.rng_advance(net.rng)
+
+    def timed_train_step(self, x, labels):
+        """One iteration with HIP-event timing per phase (synchronises): {'forward': ms, 'backward': ms, 'optimizer': ms}."""
+        net, red = self.net, self.reducer
+        net.train()
+        t = PhaseTimer()
+        with t.phase("sync_buffers"):
+            red.sync_buffers()
+        tape = Tape()
+        tape.param_ready_hook = red.param_ready
+        red.begin_backward()
+        with t.phase("forward"):
+            self._forward_loss(x, labels, tape)
+        with t.phase("backward"):
+            tape.backward()
+        with t.phase("optimizer"):
+            red.finish_and_step()
+        from .. import ops
+        ops.rng_advance(net.rng)
+        return t.result()
 
     def eval_step(self, x, labels):
         self.net.eval()

@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes
 import hashlib
 import logging
+import os
 
 import torch
 import torch.distributed as dist
@@ -56,11 +57,15 @@ def plan_buckets(store: ParamStore, first_mb=DEFAULT_FIRST_BUCKET_MB, cap_mb=DEF
 
 class GradReducer:
     def __init__(self, store: ParamStore, optimizer, first_mb=DEFAULT_FIRST_BUCKET_MB, cap_mb=DEFAULT_BUCKET_CAP_MB,
-                 broadcast_buffers=True, sync_mode=False, process_group=None):
+                 broadcast_buffers=True, sync_mode=False, process_group=None, native_comm=None):
         self.store, self.opt = store, optimizer
         self.pg = process_group
-        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
+        self.native = native_comm            # NativeRcclComm: own comm stream + hipEvent fencing (csrc/comm)
+        if native_comm is not None:
+            self.world, self.rank = native_comm.world, native_comm.rank
+        else:
+            self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
         self.buckets = plan_buckets(store, first_mb, cap_mb)
         self.bucket_of = {}
         for bi, bk in enumerate(self.buckets):
@@ -68,11 +73,18 @@ class GradReducer:
                 self.bucket_of[s.index] = bi
         self.broadcast_buffers = broadcast_buffers
         self.sync_mode = sync_mode            # debug: run every collective synchronously (race detection aid)
+        # DPA_FORCE_COLLECTIVES=1: issue every collective even at world_size 1 (single-GPU rehearsal of the RCCL
+        # stream/event path; a 1-rank all-reduce is the identity)
+        self.force = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
         self._pending = None
         self._works = None
         self.comm_bytes = sum((b["hi"] - b["lo"]) * 4 for b in self.buckets)
         optimizer.set_grad_scale(1.0 / self.world)
-        if self.world > 1:
+        if self.native is not None:
+            for t in (self.store.p, self.store.b, self.store.nbt):
+                self.native.broadcast(t, 0)
+            self.store.refresh_compute_copy()
+        elif self.world > 1 or self.force:
             self._verify_and_broadcast()
 
     # ------------------------------------------------------------------ wrap-time sync (X2, X3)
@@ -92,7 +104,11 @@ class GradReducer:
     # ------------------------------------------------------------------ per step
     def sync_buffers(self):
         """DDP's per-forward buffer broadcast (X4): rank 0's BatchNorm running statistics overwrite everyone's."""
-        if self.world > 1 and self.broadcast_buffers and self.store.b_size > 0:
+        if (self.world > 1 or self.force) and self.broadcast_buffers and self.store.b_size > 0:
+            if self.native is not None:
+                self.native.broadcast(self.store.b, 0)
+                self.native.broadcast(self.store.nbt, 0)
+                return
             dist.broadcast(self.store.b, 0, group=self.pg)
             dist.broadcast(self.store.nbt, 0, group=self.pg)
 
@@ -109,10 +125,14 @@ class GradReducer:
             self._launch(bi)
 
     def _launch(self, bi):
-        if self.world == 1:
-            return
         bk = self.buckets[bi]
         sl = self.store.g[bk["lo"]: bk["hi"]]
+        if self.native is not None:          # also exercised at world_size 1: real stream/event path on one GPU
+            self.native.allreduce_async(sl, bi)
+            self._works[bi] = "native"
+            return
+        if self.world == 1 and not self.force:
+            return
         if self.sync_mode:
             dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg)
         else:
@@ -125,7 +145,9 @@ class GradReducer:
                 raise RuntimeError(f"bucket {bi} never became ready: {self._pending[bi]} gradients missing "
                                    f"(a trainable parameter did not take part in backward)")
             w = self._works[bi]
-            if w is not None:
+            if w == "native":
+                self.native.wait(bi)           # hipStreamWaitEvent(compute, done[bucket])
+            elif w is not None:
                 w.wait()                       # stream-level wait on GPU; blocks on gloo
             self.opt.step_range(bk["lo"], bk["hi"])
         self.opt.finish_step()

@@ -127,9 +127,26 @@ def _build(args, gpu, rank, modelName, cfg, with_optimizer):
 
 
 def _init_dist(args, gpu, rank, cfg):
+    """Rendezvous in two stages: (1) the C++ TCP store on MASTER_PORT+1 checks that every rank of DDTNodes has arrived
+    and names the missing ones on timeout (the reference just blocks, README.md:47-49); (2) torch.distributed's
+    env:// bring-up of RCCL (GPU) or gloo (CPU) on MASTER_PORT."""
     device = _device_for(gpu)
     if args.worldSize > 1 or gpu >= 0:
+        if args.worldSize > 1 and getattr(cfg, "RENDEZVOUS_TIMEOUT_S", 0) > 0:
+            from .parallel.store import TCPStore
+            store = TCPStore(os.environ.get("MASTER_ADDR", cfg.MASTER_ADDR), int(os.environ.get("MASTER_PORT", cfg.MASTER_PORT)) + 1,
+                             is_master=(rank == 0), timeout_s=cfg.RENDEZVOUS_TIMEOUT_S)
+            try:
+                store.announce_and_wait(rank, args.worldSize, tag="join")
+                store.barrier(rank, args.worldSize, "joined")     # nobody tears the server down while others still poll
+            finally:
+                if rank != 0:
+                    store.close()
+            _STORES.append(store)
         comm.init_process_group(rank, args.worldSize, device, timeout_s=getattr(cfg, "COLLECTIVE_TIMEOUT_S", 600.0))
+
+
+_STORES = []
 
 
 def train(gpu, args):
@@ -203,6 +220,15 @@ def train(gpu, args):
                                          world_size=args.worldSize))
     finally:
         comm.destroy_process_group()
+        _close_stores()
+
+
+def _close_stores():
+    while _STORES:
+        try:
+            _STORES.pop().close()
+        except Exception:       # noqa: BLE001 - shutdown path
+            pass
 
 
 def _write_metrics(cfg, rec):
@@ -234,3 +260,4 @@ def test(gpu, args):
         return acc
     finally:
         comm.destroy_process_group()
+        _close_stores()

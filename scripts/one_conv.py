@@ -1,0 +1,22 @@
+"""Run one conv kernel a few times (for rocprofv3 --pmc): python scripts/one_conv.py H Cin Cout k stride pad [mode] [dtype]"""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributedpytorch_amd.ops import hip_conv as H
+h, ci, co, k, s, p = [int(v) for v in sys.argv[1:7]]
+mode = sys.argv[7] if len(sys.argv) > 7 else "fprop"
+dt = torch.bfloat16 if (len(sys.argv) <= 8 or sys.argv[8] == "bf16") else torch.float32
+N = 256
+ho = H.out_size(h, k, s, p)
+x = torch.randn(N, h, h, ci, device="cuda").to(dt)
+w = (torch.randn(co, k, k, ci, device="cuda") * 0.05).to(dt)
+wt = w.permute(3, 1, 2, 0).contiguous()
+y = torch.empty(N, ho, ho, co, device="cuda", dtype=dt)
+dy = torch.randn(N, ho, ho, co, device="cuda").to(dt)
+dx = torch.empty_like(x)
+dw = torch.empty(co, k, k, ci, device="cuda")
+ws = torch.empty(H.wgrad_workspace_numel(co, k * k * ci), device="cuda")
+for _ in range(3):
+    if mode == "fprop": H.conv_fprop(x, w, y, (s, s), (p, p))
+    elif mode == "dgrad": H.conv_dgrad(dy, wt, dx, (s, s), (p, p))
+    else: H.conv_wgrad(dy, x, dw, (k, k), (s, s), (p, p), workspace=ws)
+torch.cuda.synchronize()
