@@ -1,5 +1,5 @@
 // Native RCCL communicator (N2 of SURVEY.md §2.4: the role ProcessGroupNCCL plays for the reference, classif.py:86):
-// one RCCL communicator per process/GPU, a dedicated high-priority HIP stream for collectives, hipEvent fencing against
+// one RCCL communicator per process/GPU, a dedicated HIP stream for collectives, hipEvent fencing against
 // the compute stream so a gradient bucket's all-reduce overlaps the rest of backward:
 //
 //   compute stream:  ... wgrad kernels of bucket k | record(ready[k]) | more backward kernels ...   | wait(done[k]) | adam(k)
@@ -52,13 +52,18 @@ DPA_API void* dpa_comm_init(const void* id_bytes, int world, int rank, int devic
   Comm* c = new Comm();
   c->world = world; c->rank = rank; c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return nullptr; }
-  int lo = 0, hi = 0;
-  hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = numerically lowest = highest priority
-  // DPA_COMM_STREAM=blocking|nonblocking (default nonblocking), DPA_COMM_PRIORITY=high|normal (default high)
+  // Stream priority: NORMAL (0) by default, like the stream torch's ProcessGroupNCCL uses.  Measured on MI355X
+  // (ROCm 7.0 runtime, GPU_MAX_HW_QUEUES=4): with a high (-1) or low (+1) priority comm queue, a barrier packet that
+  // waits on the compute queue intermittently deadlocked against the compute queue's own wait on the comm queue
+  // (hipDeviceSynchronize never returned); equal-priority queues do not.  DPA_COMM_PRIORITY=high|low overrides.
+  int least = 0, greatest = 0;
+  hipDeviceGetStreamPriorityRange(&least, &greatest);
   const char* sf = getenv("DPA_COMM_STREAM");
   const char* sp = getenv("DPA_COMM_PRIORITY");
   unsigned flags = (sf && sf[0] == 'b') ? hipStreamDefault : hipStreamNonBlocking;
-  int prio = (sp && sp[0] == 'n') ? lo : hi;
+  int prio = 0;
+  if (sp && sp[0] == 'h') prio = greatest;
+  if (sp && sp[0] == 'l') prio = least;
   if (hipStreamCreateWithPriority(&c->stream, flags, prio) != hipSuccess) { delete c; return nullptr; }
   hipEventCreateWithFlags(&c->bc_ready, hipEventDisableTiming);
   hipEventCreateWithFlags(&c->bc_done, hipEventDisableTiming);
