@@ -197,18 +197,37 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
   };
   if constexpr (GLDS) {
-    // two stage buffers, ONE barrier per K-tile: [wait for tile kt + everyone done with tile kt-1] -> issue tile kt+1
-    // into the buffer tile kt-1 used -> MFMAs on tile kt while the DMA of kt+1 is in flight.
+    // Two stage buffers, ONE barrier per K-tile.  Per iteration: [my DMA of tile kt landed] + barrier [everyone's
+    // landed, everyone has read tile kt-1] -> read ALL fragments of tile kt into registers -> issue the DMA of tile
+    // kt+1 into the buffer tile kt-1 used -> MFMAs.  The fragment reads come BEFORE the DMA issue on purpose: the
+    // compiler puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA (it cannot tell the two
+    // buffers apart), which would wait for the prefetch right after issuing it and expose the whole global latency
+    // every K-tile (measured: 63 % MFMA utilisation in fp32, profiles/README.md).
     gen_addresses(0);
     issue_tile(0);
     for (int kt = 0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      const char* tA = smem + (kt & 1) * STAGE_BYTES;
+      const char* tB = tA + BM * 128;
+      uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wm * TM * 16 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[ks][j] = *reinterpret_cast<const uint4*>(tB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
+      }
       if (kt + 1 < nkt) { gen_addresses(kt + 1); issue_tile((kt + 1) & 1); }
-      const char* st = smem + (kt & 1) * STAGE_BYTES;
-      compute_tile(st, st + BM * 128);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) MfmaT<T>::mma(fa[ks][i], fb[ks][j], acc[i][j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {
     gen_addresses(0);
@@ -360,6 +379,11 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   }
 }
 
+static int tile_override() {
+  static const int v = [] { const char* e = getenv("DPA_CONV_TILE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 template <typename T>
 static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
   p.fd_nW = make_fastdiv(p.cls_nw > 0 ? p.cls_nw : 1); p.fd_nH = make_fastdiv(p.cls_nh > 0 ? p.cls_nh : 1);
@@ -371,7 +395,9 @@ static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
   else if (p.dC <= 64) {
     if ((p.M + 255) / 256 >= 256)     launch_cfg<T, 4, 1, 4, 4>(p, dgrad, s);   // 256 x 64
     else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
-  } else if (big_tiles >= 384)        launch_cfg<T, 2, 2, 4, 4>(p, dgrad, s);   // 128 x 128
+  } else if (tile_override() == 64)   launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);
+  else if (tile_override() == 12864)  launch_cfg<T, 2, 2, 4, 2>(p, dgrad, s);   // 128 x 64
+  else if (big_tiles >= 384)          launch_cfg<T, 2, 2, 4, 4>(p, dgrad, s);   // 128 x 128
   else                                launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
 }
 
@@ -419,6 +445,8 @@ DPA_API int dpa_conv_stats_rows(int M, int dC) {
   const long long big_tiles = (long long)((M + 127) / 128) * ((dC + 127) / 128);
   if (dC <= 32) return (M + 127) / 128;
   if (dC <= 64) return ((M + 255) / 256 >= 256) ? (M + 255) / 256 : (M + 63) / 64;
+  if (tile_override() == 64) return (M + 63) / 64;
+  if (tile_override() == 12864) return (M + 127) / 128;
   return big_tiles >= 384 ? (M + 127) / 128 : (M + 63) / 64;
 }
 DPA_API int dpa_conv_params_size() { return (int)sizeof(ConvParams); }

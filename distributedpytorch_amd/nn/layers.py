@@ -13,7 +13,7 @@ import math
 import torch
 
 from .. import ops
-from .engine import Act, Context, ParamStore, accumulate_grad, pad_to, workspace
+from .engine import Act, Context, ParamStore, accumulate_grad, pad_to, side_stream, workspace
 
 
 def _pair(v):
@@ -73,6 +73,7 @@ class Conv2d:
             self.b = store.add_vec(f"{name}.bias", cout, b_init or bias_default(cin * kh * kw), trainable)
         self.trainable = trainable
         self._wt = None
+        self._ev = None
 
     def out_hw(self, h, w):
         return (ops.out_size(h, self.ksize[0], self.stride[0], self.padding[0]),
@@ -90,26 +91,52 @@ class Conv2d:
     def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor):
         """dy is the gradient w.r.t. the raw conv output (pre-activation).  Writes dW/db, accumulates dx."""
         st = self.store
+        side = side_stream(ctx.device) if (self.trainable and x.needs_grad) else None
+        if side is not None:
+            # fork: wgrad (+ bias grad) on the side stream, dgrad on the main stream, join before anything else runs
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(), torch.cuda.Event())
+            main = torch.cuda.current_stream()
+            self._ev[0].record(main)
+            side.wait_event(self._ev[0])
+            with torch.cuda.stream(side):
+                self._wgrad(ctx, x, dy)
+                self._ev[1].record(side)
+            self._dgrad(ctx, x, dy)
+            main.wait_event(self._ev[1])
+            self._ready(ctx)
+            return
         if self.trainable:
-            if self.b is not None:
-                ops.colsum(dy, st.gview(self.b))
-                ctx.tape.ready(self.b)
-            rsc = self.ksize[0] * self.ksize[1] * x.data.shape[3]
-            ws = workspace(ctx.device, ops.wgrad_workspace_numel(pad_to(self.cout), rsc, ctx.cuda), "wgrad") if ctx.cuda else None
-            ops.conv_wgrad(dy, x.data, st.gview(self.w), self.ksize, self.stride, self.padding, workspace=ws)
-            ctx.tape.ready(self.w)
+            self._wgrad(ctx, x, dy)
+            self._ready(ctx)
         if x.needs_grad:
-            w = st.cview(self.w)
-            if self._wt is None:
-                k, r, s, c = w.shape
-                self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
-            ops.transpose_krsc(w, self._wt)
-            if x.grad is None:
-                dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
-                ops.conv_dgrad(dy, self._wt, dx, self.stride, self.padding)
-                x.grad = dx
-            else:
-                ops.conv_dgrad(dy, self._wt, x.grad, self.stride, self.padding, addend=x.grad)
+            self._dgrad(ctx, x, dy)
+
+    def _ready(self, ctx):
+        if self.b is not None:
+            ctx.tape.ready(self.b)
+        ctx.tape.ready(self.w)
+
+    def _wgrad(self, ctx, x, dy):
+        st = self.store
+        if self.b is not None:
+            ops.colsum(dy, st.gview(self.b))
+        rsc = self.ksize[0] * self.ksize[1] * x.data.shape[3]
+        ws = workspace(ctx.device, ops.wgrad_workspace_numel(pad_to(self.cout), rsc, ctx.cuda), "wgrad") if ctx.cuda else None
+        ops.conv_wgrad(dy, x.data, st.gview(self.w), self.ksize, self.stride, self.padding, workspace=ws)
+
+    def _dgrad(self, ctx, x, dy):
+        w = self.store.cview(self.w)
+        if self._wt is None:
+            k, r, s, c = w.shape
+            self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
+        ops.transpose_krsc(w, self._wt)
+        if x.grad is None:
+            dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
+            ops.conv_dgrad(dy, self._wt, dx, self.stride, self.padding)
+            x.grad = dx
+        else:
+            ops.conv_dgrad(dy, self._wt, x.grad, self.stride, self.padding, addend=x.grad)
 
     def __call__(self, ctx: Context, x: Act, relu=False, out=None) -> Act:
         y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
