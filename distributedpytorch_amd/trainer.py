@@ -40,7 +40,7 @@ def _device_for(gpu):
 def _dtype(cfg, device):
     if device.type == "cpu":
         return torch.float32
-    return torch.bfloat16 if getattr(cfg, "COMPUTE_DTYPE", "bf16") == "bf16" else torch.float32
+    return torch.bfloat16 if getattr(cfg, "COMPUTE_DTYPE", "fp32") == "bf16" else torch.float32
 
 
 def _maybe_fault(cfg, rank, step):

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""MNIST accuracy parity (BASELINE.md target 1): the engine vs a torch-eager restatement of the reference.
+
+The reference publishes no accuracy, so the bar is *measured*: the same run shape as /root/reference (ResNet-18 with a
+10-class head, input 3x224x224, Adam lr 1e-3, CrossEntropyLoss, batch 64, 2 epochs, seed 1234, 54k/6k/10k split;
+config.py:26-44, classif.py:110,124) is trained twice on ONE MI355X from the SAME initial weights on the SAME batches:
+
+  torch    plain torch.nn ResNet-18 (tests/torch_ref_models.py, torchvision's architecture) + torch.optim.Adam + autograd,
+           fp32, the reference's software stack (MIOpen / hipBLASLt kernels)
+  engine   this framework (hand-written HIP kernels, fused Adam over the arenas), fp32 and bf16
+
+Both consume the batches of the device input pipeline (rotate +-5 deg, random-resized-crop, bilinear 28->224,
+normalise; dataloader.py:101-116) so the comparison isolates the training engine.  There is no network on the box,
+so the digits are the deterministic synthetic MNIST of data/mnist.py (IDX files, same sizes) - "parity unpinned" w.r.t.
+the real MNIST files, which are not available offline.
+
+  python scripts/mnist_parity.py --out gpurun_out/mnist_parity.json [--n-train 60000 --n-test 10000 --epochs 2]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from distributedpytorch_amd.data import mnist  # noqa: E402
+from distributedpytorch_amd.models.factory import get_model  # noqa: E402
+from distributedpytorch_amd.nn.loss import Criterion  # noqa: E402
+from distributedpytorch_amd.nn.optim import ArenaOptimizer  # noqa: E402
+from distributedpytorch_amd.parallel.ddp import DistributedModel  # noqa: E402
+
+
+def make_dataset(path, batch, dtype, seed):
+    torch.manual_seed(seed)       # random_split uses the global RNG (utils.py:188-194 before dataloader.py:129)
+    return mnist.MNIST(path, batch, 224, worldSize=1, rank=0, gpu=0, device=torch.device("cuda", 0), dtype=dtype, seed=seed)
+
+
+def run_engine(path, dtype, epochs, batch, seed, init_sd=None):
+    ds = make_dataset(path, batch, dtype, seed)
+    torch.manual_seed(seed)
+    net, _ = get_model("resnet", 10, device=torch.device("cuda", 0), dtype=dtype)
+    net.seed_rng(seed)
+    if init_sd is not None:
+        net.store.load_state_dict(init_sd)
+    sd0 = {k: v.clone() for k, v in net.store.state_dict().items()}
+    dm = DistributedModel(net, Criterion("cross_entropy"), ArenaOptimizer(net.store, "adam", lr=1e-3))
+    hist = []
+    t0 = time.time()
+    for ep in range(epochs):
+        ds.sampler["train"].set_epoch(ep)
+        dm.reset_epoch_metrics()
+        for x, y in ds.iterator["train"]:
+            dm.train_step(x, y)
+        tl, ta, _ = dm.epoch_metrics()
+        dm.reset_epoch_metrics()
+        for x, y in ds.iterator["valid"]:
+            dm.eval_step(x, y)
+        vl, va, _ = dm.epoch_metrics()
+        hist.append(dict(epoch=ep + 1, train_loss=tl, train_acc=ta, valid_loss=vl, valid_acc=va))
+        print(f"  engine[{dtype}] epoch {ep + 1}: train {tl:.4f}/{ta * 100:.2f}%  valid {vl:.4f}/{va * 100:.2f}%", flush=True)
+    dm.reset_epoch_metrics()
+    for x, y in ds.iterator["test"]:
+        dm.eval_step(x, y)
+    _, test_acc, _ = dm.epoch_metrics()
+    torch.cuda.synchronize()
+    return dict(history=hist, test_acc=test_acc * 100, seconds=time.time() - t0), sd0
+
+
+def run_torch(path, epochs, batch, seed, init_sd):
+    import torch_ref_models as ref
+    ds = make_dataset(path, batch, torch.float32, seed)
+    model = ref.resnet18(10).cuda()
+    model.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in init_sd.items()}, strict=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def batches(phase):
+        for x, y in ds.iterator[phase]:
+            yield x[..., :3].permute(0, 3, 1, 2).contiguous(), y
+
+    def evaluate(phase):
+        model.eval()
+        tot_l = tot_a = 0.0
+        n = 0
+        with torch.no_grad():
+            for x, y in batches(phase):
+                out = model(x)
+                tot_l += float(crit(out, y))
+                tot_a += float((out.argmax(1) == y).float().mean())
+                n += 1
+        return tot_l / n, tot_a / n
+
+    hist = []
+    t0 = time.time()
+    for ep in range(epochs):
+        ds.sampler["train"].set_epoch(ep)
+        model.train()
+        sl = torch.zeros((), device="cuda")
+        sa = torch.zeros((), device="cuda")
+        n = 0
+        for x, y in batches("train"):
+            opt.zero_grad()
+            out = model(x)
+            loss = crit(out, y)
+            loss.backward()
+            opt.step()
+            sl += loss.detach()
+            sa += (out.argmax(1) == y).float().mean()
+            n += 1
+        vl, va = evaluate("valid")
+        hist.append(dict(epoch=ep + 1, train_loss=float(sl) / n, train_acc=float(sa) / n, valid_loss=vl, valid_acc=va))
+        print(f"  torch[fp32] epoch {ep + 1}: train {float(sl) / n:.4f}/{float(sa) / n * 100:.2f}%  valid {vl:.4f}/{va * 100:.2f}%",
+              flush=True)
+    _, test_acc = evaluate("test")
+    torch.cuda.synchronize()
+    return dict(history=hist, test_acc=test_acc * 100, seconds=time.time() - t0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-train", type=int, default=60000)
+    ap.add_argument("--n-test", type=int, default=10000)
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--data", default="")
+    a = ap.parse_args()
+    path = a.data or tempfile.mkdtemp(prefix="dpa_mnist_")
+    if not mnist.have_mnist(path):
+        mnist.generate_synthetic_mnist(path, n_train=a.n_train, n_test=a.n_test, seed=a.seed)
+    res = {"config": vars(a), "data": "synthetic MNIST (data/mnist.py generator; real MNIST is not available offline)"}
+    print("engine fp32", flush=True)
+    res["engine_fp32"], sd0 = run_engine(path, torch.float32, a.epochs, a.batch, a.seed)
+    print("torch eager fp32 (reference restatement)", flush=True)
+    res["torch_fp32"] = run_torch(path, a.epochs, a.batch, a.seed, sd0)
+    print("engine bf16", flush=True)
+    res["engine_bf16"], _ = run_engine(path, torch.bfloat16, a.epochs, a.batch, a.seed, init_sd=sd0)
+    summary = {k: round(res[k]["test_acc"], 2) for k in ("torch_fp32", "engine_fp32", "engine_bf16")}
+    res["summary_test_acc_percent"] = summary
+    res["summary_seconds"] = {k: round(res[k]["seconds"], 1) for k in ("torch_fp32", "engine_fp32", "engine_bf16")}
+    print(json.dumps({"test_acc_percent": summary, "seconds": res["summary_seconds"]}), flush=True)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as fh:
+            json.dump(res, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
