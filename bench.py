@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU only)")
     ap.add_argument("--no-broadcast-buffers", action="store_true")
+    ap.add_argument("--comm", default=os.environ.get("DPA_COMM_BACKEND", "torch"), choices=["torch", "rccl_native"],
+                    help="gradient all-reduce through torch.distributed's RCCL group (default) or the C++ communicator")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,6 +64,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         comm.init_process_group(rank, world, device)
 
+    native_comm = None
+    if args.comm == "rccl_native":
+        from distributedpytorch_amd.trainer import make_native_comm
+        native_comm = make_native_comm(rank, world, device, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                       int(os.environ.get("MASTER_PORT", "29511")) + 2)
+
     shapes = {"imagenet": (224, 1000, False), "cifar": (32, 10, True), "mnist": (224, 10, False)}
     side, classes, small = shapes[args.shape]
 
@@ -77,7 +85,7 @@ def main():
         net, _ = get_model(args.model, classes, device=device, dtype=dtype, small_input=small)
         opt = ArenaOptimizer(net.store, args.optimizer, lr=1e-3)
         dm = DistributedModel(net, Criterion("cross_entropy"), opt, bucket_cap_mb=args.bucket_mb,
-                              broadcast_buffers=not args.no_broadcast_buffers)
+                              broadcast_buffers=not args.no_broadcast_buffers, native_comm=native_comm)
         # synthetic, device-resident batch (NHWC, 3 real channels padded to the kernels' 8-channel granule)
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         x = torch.zeros(args.batch, side, side, net.in_channels, device=device, dtype=dtype)
@@ -126,10 +134,12 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, device-resident batch)",
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch, "seq_len": None,
                        "image": f"{side}x{side}x3", "classes": classes, "optimizer": args.optimizer,
-                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "hipgraph": use_graph,
+                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "comm": args.comm, "hipgraph": use_graph,
                        "mean_loss": round(loss, 4)},
             "secondary": secondary,
         }), flush=True)
+    if native_comm is not None:
+        native_comm.destroy()
     if world > 1 or force:
         comm.destroy_process_group()
     return 0

@@ -64,6 +64,7 @@ COMPUTE_DTYPE = _env("COMPUTE_DTYPE", 'fp32')     # fp32 (exact f32 MFMA; the re
 FIRST_BUCKET_MB = _env("FIRST_BUCKET_MB", 1.0, float)    # DDP first (last-layer) bucket
 BUCKET_CAP_MB = _env("BUCKET_CAP_MB", 25.0, float)       # DDP bucket cap, sized for 7 xGMI links per GPU
 BROADCAST_BUFFERS = _env("BROADCAST_BUFFERS", True, bool)  # DDP semantics: rank 0's BatchNorm statistics win every step
+COMM_BACKEND = _env("COMM_BACKEND", 'torch')       # torch (torch.distributed: RCCL process group / gloo) | rccl_native (C++ communicator + reducer core, csrc/comm)
 USE_HIPGRAPH = _env("USE_HIPGRAPH", True, bool)   # replay the training iteration from a hipGraph when world_size == 1
 SYNC_COMM = _env("SYNC_COMM", False, bool)        # debug: synchronous collectives (race-detection aid)
 GLOBAL_METRICS = _env("GLOBAL_METRICS", False, bool)  # all-reduce (loss, acc) over ranks; False = reference behaviour

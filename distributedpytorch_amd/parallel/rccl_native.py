@@ -10,14 +10,26 @@ import torch
 from ..ops import native
 
 
-def _lib():
-    path = native.lib_path("libdpamd_comm.so")
-    if not os.path.exists(path):
-        raise RuntimeError(f"{path} is missing: run `python -m distributedpytorch_amd.csrc.build`")
-    lib = ctypes.CDLL(path)
-    lib.dpa_comm_init.restype = ctypes.c_void_p
-    lib.dpa_comm_last_error.restype = ctypes.c_char_p
-    return lib
+_LIB = None
+
+
+def comm_lib():
+    """libdpamd_comm.so: native RCCL communicator + gradient reducer core (csrc/comm/*.cpp)."""
+    global _LIB
+    if _LIB is None:
+        path = native.lib_path("libdpamd_comm.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m distributedpytorch_amd.csrc.build`")
+        lib = ctypes.CDLL(path)
+        lib.dpa_comm_init.restype = ctypes.c_void_p
+        lib.dpa_comm_last_error.restype = ctypes.c_char_p
+        lib.dpa_reducer_create.restype = ctypes.c_void_p
+        lib.dpa_reducer_launched_bytes.restype = ctypes.c_longlong
+        _LIB = lib
+    return _LIB
+
+
+_lib = comm_lib
 
 
 class NativeRcclComm:

@@ -71,6 +71,7 @@ class GradReducer:
         for bi, bk in enumerate(self.buckets):
             for s in bk["params"]:
                 self.bucket_of[s.index] = bi
+        self._core_lib, self._core = self._make_core()
         self.broadcast_buffers = broadcast_buffers
         self.sync_mode = sync_mode            # debug: run every collective synchronously (race detection aid)
         # DPA_FORCE_COLLECTIVES=1: issue every collective even at world_size 1 (single-GPU rehearsal of the RCCL
@@ -86,6 +87,37 @@ class GradReducer:
             self.store.refresh_compute_copy()
         elif self.world > 1 or self.force:
             self._verify_and_broadcast()
+
+    def _make_core(self):
+        """The C++ reducer core (csrc/comm/reducer.cpp): pending counters, ready detection, launch of the bucket's
+        all-reduce on the native communicator's stream.  With the torch.distributed backend (RCCL process group or
+        gloo) the core does the bookkeeping and this class issues the collective for the bucket it returns."""
+        from .rccl_native import comm_lib
+        lib = comm_lib()
+        n = len(self.store.params)
+        bo = (ctypes.c_int * n)(*[self.bucket_of.get(s.index, -1) for s in self.store.params])
+        assert all(s.index == i for i, s in enumerate(self.store.params))
+        nb = len(self.buckets)
+        lo = (ctypes.c_longlong * max(nb, 1))(*[b["lo"] for b in self.buckets])
+        hi = (ctypes.c_longlong * max(nb, 1))(*[b["hi"] for b in self.buckets])
+        comm_h = ctypes.c_void_p(self.native.h) if self.native is not None else ctypes.c_void_p(0)
+        core = lib.dpa_reducer_create(comm_h, ctypes.c_void_p(self.store.g.data_ptr()), n, bo, nb, lo, hi)
+        if not core:
+            raise RuntimeError("dpa_reducer_create failed (bucket plan out of range)")
+        return lib, ctypes.c_void_p(core)
+
+    def _stream(self):
+        if self.store.device.type == "cuda":
+            return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_core", None):
+                self._core_lib.dpa_reducer_destroy(self._core)
+                self._core = None
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ wrap-time sync (X2, X3)
     def _verify_and_broadcast(self):
@@ -113,24 +145,26 @@ class GradReducer:
             dist.broadcast(self.store.nbt, 0, group=self.pg)
 
     def begin_backward(self):
-        self._pending = [len(b["params"]) for b in self.buckets]
+        self._core_lib.dpa_reducer_begin(self._core)
         self._works = [None] * len(self.buckets)
 
     def param_ready(self, spec):
-        bi = self.bucket_of.get(spec.index)
-        if bi is None:
-            return
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        """Backward-tape hook: the gradient kernel of `spec` has been queued on the current stream."""
+        bi = self._core_lib.dpa_reducer_param_ready(self._core, spec.index, self._stream())
+        if bi >= 0:
+            if self.native is not None:
+                self._works[bi] = "native"        # the core enqueued ncclAllReduce on the comm stream
+            else:
+                self._launch(bi)
+        elif bi == -2:
+            raise RuntimeError(f"reducer protocol error: gradient of {spec.name} reported ready twice in one backward")
+        elif bi == -3:
+            raise RuntimeError(f"RCCL all-reduce could not be enqueued for the bucket of {spec.name}")
 
     def _launch(self, bi):
+        """torch.distributed backend (RCCL process group on GPUs, gloo on CPUs): async all-reduce of bucket bi."""
         bk = self.buckets[bi]
         sl = self.store.g[bk["lo"]: bk["hi"]]
-        if self.native is not None:          # also exercised at world_size 1: real stream/event path on one GPU
-            self.native.allreduce_async(sl, bi)
-            self._works[bi] = "native"
-            return
         if self.world == 1 and not self.force:
             return
         if self.sync_mode:
@@ -140,14 +174,17 @@ class GradReducer:
 
     def finish_and_step(self):
         """Wait for each bucket in ready order and launch its optimizer update right away."""
+        stream = self._stream()
         for bi, bk in enumerate(self.buckets):
-            if self._pending[bi] != 0:
-                raise RuntimeError(f"bucket {bi} never became ready: {self._pending[bi]} gradients missing "
+            rc = self._core_lib.dpa_reducer_wait_bucket(self._core, bi, stream)   # native: hipStreamWaitEvent(done[b])
+            if rc == 1:
+                missing = self._core_lib.dpa_reducer_pending(self._core, bi)
+                raise RuntimeError(f"bucket {bi} never became ready: {missing} gradients missing "
                                    f"(a trainable parameter did not take part in backward)")
+            if rc != 0:
+                raise RuntimeError(f"waiting for the all-reduce of bucket {bi} failed")
             w = self._works[bi]
-            if w == "native":
-                self.native.wait(bi)           # hipStreamWaitEvent(compute, done[bucket])
-            elif w is not None:
+            if w is not None and w != "native":
                 w.wait()                       # stream-level wait on GPU; blocks on gloo
             self.opt.step_range(bk["lo"], bk["hi"])
         self.opt.finish_step()

@@ -122,7 +122,7 @@ def _build(args, gpu, rank, modelName, cfg, with_optimizer):
     dmodel = DistributedModel(net, criterion, optimizer, first_bucket_mb=getattr(cfg, "FIRST_BUCKET_MB", 1.0),
                               bucket_cap_mb=getattr(cfg, "BUCKET_CAP_MB", 25.0),
                               broadcast_buffers=getattr(cfg, "BROADCAST_BUFFERS", True),
-                              sync_comm=getattr(cfg, "SYNC_COMM", False))
+                              sync_comm=getattr(cfg, "SYNC_COMM", False), native_comm=_NATIVE[-1] if _NATIVE else None)
     return device, dataset, net, dmodel, optimizer, scheduler
 
 
@@ -144,9 +144,34 @@ def _init_dist(args, gpu, rank, cfg):
                     store.close()
             _STORES.append(store)
         comm.init_process_group(rank, args.worldSize, device, timeout_s=getattr(cfg, "COLLECTIVE_TIMEOUT_S", 600.0))
+        if getattr(cfg, "COMM_BACKEND", "torch") == "rccl_native" and device.type == "cuda":
+            _NATIVE.append(make_native_comm(rank, args.worldSize, device,
+                                            os.environ.get("MASTER_ADDR", cfg.MASTER_ADDR),
+                                            int(os.environ.get("MASTER_PORT", cfg.MASTER_PORT)) + 2))
+
+
+def make_native_comm(rank, world, device, addr, port, timeout_s=300.0):
+    """The C++ RCCL communicator (csrc/comm/rccl_comm.cpp): rank 0 creates the ncclUniqueId and publishes it through
+    the C++ TCP store (N1), every rank joins with ncclCommInitRank.  World size 1 needs no store."""
+    from .parallel.rccl_native import NativeRcclComm
+    store = None
+    if world > 1:
+        from .parallel.store import TCPStore
+        store = TCPStore(addr, port, is_master=(rank == 0), timeout_s=timeout_s)
+    try:
+        nc = NativeRcclComm(store, rank, world, device.index or 0)
+        if store is not None:
+            store.barrier(rank, world, "rccl_up")
+    finally:
+        if store is not None and rank != 0:
+            store.close()
+    if store is not None and rank == 0:
+        _STORES.append(store)
+    return nc
 
 
 _STORES = []
+_NATIVE = []
 
 
 def train(gpu, args):
@@ -224,6 +249,15 @@ def train(gpu, args):
 
 
 def _close_stores():
+    while _NATIVE:
+        try:
+            nc = _NATIVE.pop()
+            if nc.async_error() != 0:
+                nc.abort()
+            else:
+                nc.destroy()
+        except Exception:       # noqa: BLE001 - shutdown path
+            pass
     while _STORES:
         try:
             _STORES.pop().close()

@@ -309,3 +309,37 @@ def test_checkpoint_loads_into_reference_style_torch_model(tmp_path):
     torch.testing.assert_close(net2.store.p, net.store.p)
     torch.testing.assert_close(opt2.m, opt.m)
     net2.load_state_dict(model.module.state_dict())                   # un-prefixed keys
+
+
+def test_native_reducer_core_protocol():
+    """csrc/comm/reducer.cpp bookkeeping (no communicator): ready detection, double-ready and missing-gradient errors,
+    plan-order diagnostics - the stream/event-free half of the T1 'reducer discipline' tests."""
+    import ctypes
+    from distributedpytorch_amd.parallel.rccl_native import comm_lib
+    lib = comm_lib()
+    # 5 params: p0 frozen, buckets in backward order: b0 = {p4}, b1 = {p3, p2}, b2 = {p1}
+    bucket_of = (ctypes.c_int * 5)(-1, 2, 1, 1, 0)
+    lo = (ctypes.c_longlong * 3)(300, 100, 0)
+    hi = (ctypes.c_longlong * 3)(400, 300, 100)
+    g = torch.zeros(400)
+    core = ctypes.c_void_p(lib.dpa_reducer_create(None, ctypes.c_void_p(g.data_ptr()), 5, bucket_of, 3, lo, hi))
+    assert core
+    lib.dpa_reducer_begin(core)
+    assert lib.dpa_reducer_param_ready(core, 0, None) == -1            # frozen
+    assert lib.dpa_reducer_param_ready(core, 4, None) == 0             # bucket 0 complete
+    assert lib.dpa_reducer_param_ready(core, 3, None) == -1
+    assert lib.dpa_reducer_param_ready(core, 3, None) == -2            # reported twice
+    assert lib.dpa_reducer_wait_bucket(core, 1, None) == 1             # p2 still missing
+    assert lib.dpa_reducer_pending(core, 1) == 1
+    assert lib.dpa_reducer_param_ready(core, 2, None) == 1
+    assert lib.dpa_reducer_param_ready(core, 1, None) == 2
+    assert [lib.dpa_reducer_wait_bucket(core, b, None) for b in range(3)] == [0, 0, 0]
+    assert lib.dpa_reducer_order_violations(core) == 0
+    assert lib.dpa_reducer_launched_bytes(core) == 400 * 4
+    lib.dpa_reducer_begin(core)                                        # next iteration, out-of-plan order
+    assert lib.dpa_reducer_param_ready(core, 1, None) == 2
+    assert lib.dpa_reducer_order_violations(core) == 1
+    assert lib.dpa_reducer_param_ready(core, 9, None) == -2            # unknown parameter
+    lib.dpa_reducer_destroy(core)
+    bad = (ctypes.c_int * 1)(7)
+    assert not lib.dpa_reducer_create(None, None, 1, bad, 3, lo, hi)   # bucket index out of range
