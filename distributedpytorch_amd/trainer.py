@@ -73,6 +73,9 @@ def processData(gpu, phase, epoch, dmodel: DistributedModel, modelName, dataset,
                 dmodel.replay_train_step(inputs, labels)
             else:
                 dmodel.train_step(inputs, labels)
+            if _NATIVE and i % 50 == 49 and _NATIVE[-1].async_error() != 0:      # ncclCommGetAsyncError
+                _NATIVE[-1].abort()
+                raise RuntimeError(f"RCCL reported an asynchronous error on rank {rank}; communicator aborted")
         else:
             dmodel.eval_step(inputs, labels)
         if gpu <= 0 and train:
