@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--comm", default=os.environ.get("DPA_COMM_BACKEND", "torch"), choices=["torch", "rccl_native"],
                     help="gradient all-reduce through torch.distributed's RCCL group (default) or the C++ communicator")
     args = ap.parse_args()
+    if os.environ.get("DPA_WATCHDOG_S"):      # hang diagnosis: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DPA_WATCHDOG_S"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -51,8 +54,15 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "bench.py needs an MI355X (no GPU visible)"}))
         return 2
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank
+    if os.environ.get("DPA_SHARE_GPU", "0") == "1":       # plumbing rehearsal: several ranks on one GPU (with DPA_DIST_BACKEND=gloo)
+        dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if os.environ.get("DPA_COMPUTE_STREAM", "own") == "own":
+        # compute on an explicit non-blocking stream: the legacy null stream synchronises implicitly with every
+        # blocking stream any library creates, which is neither needed nor wanted next to the collectives' streams
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     from distributedpytorch_amd.models.factory import get_model
     from distributedpytorch_amd.nn.loss import Criterion

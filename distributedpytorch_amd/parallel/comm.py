@@ -30,11 +30,14 @@ def init_process_group(rank, world_size, device, timeout_s=600.0, master_addr=No
         os.environ["MASTER_PORT"] = str(master_port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver stack
     backend = "nccl" if device.type == "cuda" else "gloo"
+    # DPA_DIST_BACKEND=gloo: rehearse multi-rank runs with several processes sharing ONE GPU (RCCL refuses two ranks
+    # on one device; gloo stages CUDA tensors through the host) - plumbing check only, not a performance path
+    backend = os.environ.get("DPA_DIST_BACKEND", backend)
     if device.type == "cuda":
         warm_kernel_library(device)
     kwargs = dict(backend=backend, init_method="env://", world_size=world_size, rank=rank,
                   timeout=datetime.timedelta(seconds=timeout_s))
-    if device.type == "cuda":
+    if device.type == "cuda" and backend == "nccl":
         kwargs["device_id"] = device
     try:
         dist.init_process_group(**kwargs)

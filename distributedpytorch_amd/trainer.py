@@ -30,10 +30,20 @@ def _cfg():
     return config
 
 
+_COMPUTE_STREAMS = {}
+
+
 def _device_for(gpu):
     if gpu >= 0 and torch.cuda.is_available():
         torch.cuda.set_device(gpu)
-        return torch.device("cuda", gpu)
+        dev = torch.device("cuda", gpu)
+        if gpu not in _COMPUTE_STREAMS and os.environ.get("DPA_COMPUTE_STREAM", "own") == "own":
+            # explicit non-blocking compute stream (the legacy null stream synchronises implicitly with every
+            # blocking stream a library creates)
+            _COMPUTE_STREAMS[gpu] = torch.cuda.Stream(device=dev)
+        if gpu in _COMPUTE_STREAMS:
+            torch.cuda.set_stream(_COMPUTE_STREAMS[gpu])
+        return dev
     return torch.device("cpu")
 
 
