@@ -42,6 +42,8 @@ struct ConvParams {
   int Kg;            // R*S*sC
   int relu;          // apply max(.,0) in the epilogue
   int no_uni;        // debug / A-B switch: force the general address path (DPA_CONV_UNI=0)
+  int m_off;         // first GEMM row of this launch (a conv may be split into a big-tile and a small-tile launch)
+  int stats_row0;    // first stats-slab row of this launch
   int tilesM, tilesN;
   // dgrad "parity class" geometry: output pixels with (hi+ph) % sh == a, (wi+pw) % sw == b form a dense sub-problem
   // that only sees taps r = a + sh*t, s = b + sw*t (stride-1 convs are the single class a = b = 0).

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = p.m_off + tm * BM, n0 = tn * BN;
 
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
-      if (n0 + col < p.dC) p.stats[((size_t)tm * 2 + which) * p.dC + n0 + col] = s;
+      if (n0 + col < p.dC) p.stats[((size_t)(p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
     }
   }
 }
@@ -356,7 +356,7 @@ template <typename T, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   ConvParams p = pin;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  p.tilesM = (p.M + BM - 1) / BM;
+  p.tilesM = (p.M - p.m_off + BM - 1) / BM;
   p.tilesN = (p.dC + BN - 1) / BN;
   // staging policy: LDS-DMA + 2 stage buffers pays when there are enough K-tiles to pipeline; short reductions
   // (1x1 convs on few channels) run more blocks per CU with the single-buffer register-staged variant.
@@ -384,12 +384,32 @@ static int tile_override() {
   return v;
 }
 
+// Rows [0, split) go to 128 x 128 tiles, rows [split, M) to 64 x 64 tiles; 0 = no split.  Shared by the launcher and
+// by dpa_conv_stats_rows (the stats slab has one row per M-tile of either size).
+static int tail_split_rows(int M, int dC) {
+  static const int enabled = [] { const char* e = getenv("DPA_CONV_TAILSPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!enabled) return 0;
+  // The 128 x 128 kernel is resident twice per CU and the dispatcher refills freed slots two at a time, so the
+  // quantum that matters is a ROUND of 2 x 256 tiles (measured: 512 tiles 318 us, 784 tiles 595 us, 1024 tiles 592 us
+  // in fp32, scripts/conv_size_sweep.py).  Split only when the last round would be at most a quarter full: its rows
+  // then become <= 512 quarter-size tiles, i.e. at most two per CU.
+  const int CUS = 512;
+  const long long tm = (M + 127) / 128, tn = (dC + 127) / 128, tiles = tm * tn;
+  const long long full = tiles / CUS;                 // whole rounds
+  const long long rem = tiles - full * CUS;           // tiles of the last, partial round
+  if (full < 1 || rem == 0 || rem * 4 > CUS) return 0;
+  const long long big_rows = (full * CUS) / tn;       // M-tiles kept as big tiles
+  if (big_rows <= 0 || big_rows >= tm) return 0;
+  return (int)(big_rows * 128);
+}
+
 template <typename T>
 static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
   p.fd_nW = make_fastdiv(p.cls_nw > 0 ? p.cls_nw : 1); p.fd_nH = make_fastdiv(p.cls_nh > 0 ? p.cls_nh : 1);
   p.fd_sC = make_fastdiv(p.sC); p.fd_nS = make_fastdiv(p.nS > 0 ? p.nS : 1);
   // tile selection: narrow outputs get a tall tile; small problems get small tiles so that the grid
   // still covers the 256 CUs.
+  p.m_off = 0; p.stats_row0 = 0;
   const long long big_tiles = (long long)((p.M + 127) / 128) * ((p.dC + 127) / 128);
   if (p.dC <= 32)                     launch_cfg<T, 4, 1, 2, 2>(p, dgrad, s);   // 128 x 32
   else if (p.dC <= 64) {
@@ -397,8 +417,20 @@ static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
     else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
   } else if (tile_override() == 64)   launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);
   else if (tile_override() == 12864)  launch_cfg<T, 2, 2, 4, 2>(p, dgrad, s);   // 128 x 64
-  else if (big_tiles >= 384)          launch_cfg<T, 2, 2, 4, 4>(p, dgrad, s);   // 128 x 128
-  else                                launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
+  else if (big_tiles >= 384) {
+    // 128 x 128 tiles run in rounds of 512 (2 per CU); a nearly empty last round costs a full round.  Give whole
+    // rounds to the big tiles and the few remaining rows to a second launch of 64 x 64 tiles (quarter-size work
+    // items that spread over the chip): e.g. 1568 tiles = 3.06 rounds -> 3 rounds + a short tail instead of 4.
+    const int split = tail_split_rows(p.M, p.dC);
+    if (split > 0) {
+      ConvParams a = p; a.M = split;
+      launch_cfg<T, 2, 2, 4, 4>(a, dgrad, s);
+      ConvParams b = p; b.m_off = split; b.stats_row0 = split / 128;
+      launch_cfg<T, 2, 2, 2, 2>(b, dgrad, s);
+    } else {
+      launch_cfg<T, 2, 2, 4, 4>(p, dgrad, s);
+    }
+  } else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
 }
 
 template <typename T>
@@ -447,6 +479,10 @@ DPA_API int dpa_conv_stats_rows(int M, int dC) {
   if (dC <= 64) return ((M + 255) / 256 >= 256) ? (M + 255) / 256 : (M + 63) / 64;
   if (tile_override() == 64) return (M + 63) / 64;
   if (tile_override() == 12864) return (M + 127) / 128;
-  return big_tiles >= 384 ? (M + 127) / 128 : (M + 63) / 64;
+  if (big_tiles >= 384) {
+    const int split = tail_split_rows(M, dC);
+    return split > 0 ? split / 128 + (M - split + 63) / 64 : (M + 127) / 128;
+  }
+  return (M + 63) / 64;
 }
 DPA_API int dpa_conv_params_size() { return (int)sizeof(ConvParams); }

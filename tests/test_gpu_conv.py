@@ -18,6 +18,8 @@ SHAPES = [
     (3, 17, 13, 24, 40, 5, 1, 2),      # odd sizes, channels not multiples of the tile
     (2, 20, 20, 16, 48, 11, 4, 2),     # alexnet-like stem
     (64, 1, 1, 512, 16, 1, 1, 0),      # linear as 1x1 conv
+    (65, 32, 32, 128, 128, 3, 1, 1),   # 520 big tiles = 1.02 rounds: tail-split launch (128x128 body + 64x64 tail)
+    (260, 32, 32, 128, 128, 3, 2, 1),  # tail split in fprop and in each stride-2 dgrad parity class
 ]
 
 
