@@ -85,8 +85,21 @@ class Conv2d:
         if out is None:
             out = ctx.empty((n, ho, wo, pad_to(self.cout)))
         bias = self.store.view(self.b) if self.b is not None else None
-        ops.conv_fprop(x, self.store.cview(self.w), out, self.stride, self.padding, bias=bias, relu=relu, stats=stats)
+        w = self.store.cview(self.w)
+        if self._as_gemm(x):      # whole-map 'valid' kernel = plain GEMM over the flattened (h, w, c) features
+            ops.conv_fprop(x.view(n, 1, 1, -1), w.view(w.shape[0], 1, 1, -1), out, (1, 1), (0, 0), bias=bias, relu=relu,
+                           stats=stats)
+        else:
+            ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats)
         return out
+
+    def _as_gemm(self, x: torch.Tensor) -> bool:
+        """True when this is a Linear over a spatial map (kernel == map, no padding): NHWC activations and KRSC weights
+        flatten to [N, h*w*c] and [Cout, h*w*c] without a copy, so fprop / dgrad / wgrad run as a 1x1 GEMM instead of a
+        kh x kw convolution whose dgrad would visit kh*kw taps per input pixel with all but one masked (AlexNet fc1:
+        4.2 ms -> one 64 x 9216 x 4096 GEMM)."""
+        return (self.ksize != (1, 1) and tuple(x.shape[1:3]) == self.ksize and self.padding == (0, 0)
+                and x.is_contiguous() and x.shape[3] == self.store.cview(self.w).shape[3])
 
     def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor):
         """dy is the gradient w.r.t. the raw conv output (pre-activation).  Writes dW/db, accumulates dx."""
@@ -123,20 +136,31 @@ class Conv2d:
             ops.colsum(dy, st.gview(self.b))
         rsc = self.ksize[0] * self.ksize[1] * x.data.shape[3]
         ws = workspace(ctx.device, ops.wgrad_workspace_numel(pad_to(self.cout), rsc, ctx.cuda), "wgrad") if ctx.cuda else None
-        ops.conv_wgrad(dy, x.data, st.gview(self.w), self.ksize, self.stride, self.padding, workspace=ws)
+        gw = st.gview(self.w)
+        if self._as_gemm(x.data):
+            ops.conv_wgrad(dy, x.data.view(x.data.shape[0], 1, 1, -1), gw.view(gw.shape[0], 1, 1, -1), (1, 1), (1, 1), (0, 0),
+                           workspace=ws)
+        else:
+            ops.conv_wgrad(dy, x.data, gw, self.ksize, self.stride, self.padding, workspace=ws)
 
     def _dgrad(self, ctx, x, dy):
         w = self.store.cview(self.w)
-        if self._wt is None:
+        gemm = self._as_gemm(x.data) and (x.grad is None or x.grad.is_contiguous()) \
+            and (x.grad_buf is None or x.grad_buf.is_contiguous())
+        if gemm:
+            w = w.view(w.shape[0], 1, 1, -1)
+        if self._wt is None or self._wt.shape[0] != w.shape[3]:
             k, r, s, c = w.shape
             self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
         ops.transpose_krsc(w, self._wt)
+        stride, padding = ((1, 1), (0, 0)) if gemm else (self.stride, self.padding)
+        flat = (lambda t: t.view(t.shape[0], 1, 1, -1)) if gemm else (lambda t: t)
         if x.grad is None:
             dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
-            ops.conv_dgrad(dy, self._wt, dx, self.stride, self.padding)
+            ops.conv_dgrad(dy, self._wt, flat(dx), stride, padding)
             x.grad = dx
         else:
-            ops.conv_dgrad(dy, self._wt, x.grad, self.stride, self.padding, addend=x.grad)
+            ops.conv_dgrad(dy, self._wt, flat(x.grad), stride, padding, addend=flat(x.grad))
 
     def __call__(self, ctx: Context, x: Act, relu=False, out=None) -> Act:
         y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
