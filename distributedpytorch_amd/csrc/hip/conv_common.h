@@ -44,6 +44,9 @@ struct ConvParams {
   int no_uni;        // debug / A-B switch: force the general address path (DPA_CONV_UNI=0)
   int m_off;         // first GEMM row of this launch (a conv may be split into a big-tile and a small-tile launch)
   int stats_row0;    // first stats-slab row of this launch
+  int splitK;        // > 1: blockIdx = split * tiles + tile; raw fp32 partial sums go to `ws`, epilogue in the reduce kernel
+  int kt_per_split;  // K-tiles per split
+  float* ws;         // split-K workspace [splitK][M][dC]
   int tilesM, tilesN;
   // dgrad "parity class" geometry: output pixels with (hi+ph) % sh == a, (wi+pw) % sw == b form a dense sub-problem
   // that only sees taps r = a + sh*t, s = b + sw*t (stride-1 convs are the single class a = b = 0).

@@ -14,6 +14,8 @@
 //   tile is staged through LDS so global stores are 16 B per lane along the channel dimension, at an
 //   arbitrary channel offset/stride of the destination buffer (zero-copy concat).
 #include "conv_common.h"
+#include <map>
+#include <mutex>
 #include <cstdlib>
 
 // 64 zero bytes: the source of every padded / out-of-range 16-byte chunk of the LDS-DMA staging path
@@ -33,7 +35,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = p.tilesM * p.tilesN;
+  const int split = p.splitK > 1 ? (int)blockIdx.x / ntiles : 0;      // block-uniform
+  const int tile = xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
   const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
   const int m0 = p.m_off + tm * BM, n0 = tn * BN;
 
@@ -178,7 +182,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = (p.Kg + BKE - 1) / BKE;
+  const int nkt_all = (p.Kg + BKE - 1) / BKE;
+  const int kt0 = p.splitK > 1 ? split * p.kt_per_split : 0;
+  const int nkt = p.splitK > 1 ? min(nkt_all, kt0 + p.kt_per_split) : nkt_all;     // this block reduces K-tiles [kt0, nkt)
   const int fr = lane & 15, fq = lane >> 4;
   auto compute_tile = [&](const char* tA, const char* tB) __attribute__((always_inline)) {
 #pragma unroll
@@ -203,12 +209,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     // compiler puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA (it cannot tell the two
     // buffers apart), which would wait for the prefetch right after issuing it and expose the whole global latency
     // every K-tile (measured: 63 % MFMA utilisation in fp32, profiles/README.md).
-    gen_addresses(0);
-    issue_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    if (kt0 < nkt) { gen_addresses(kt0); issue_tile(0); }
+    for (int kt = kt0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const char* tA = smem + (kt & 1) * STAGE_BYTES;
+      const char* tA = smem + ((kt - kt0) & 1) * STAGE_BYTES;
       const char* tB = tA + BM * 128;
       uint4 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         for (int j = 0; j < TN; ++j)
           fb[ks][j] = *reinterpret_cast<const uint4*>(tB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
       }
-      if (kt + 1 < nkt) { gen_addresses(kt + 1); issue_tile((kt + 1) & 1); }
+      if (kt + 1 < nkt) { gen_addresses(kt + 1); issue_tile((kt + 1 - kt0) & 1); }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -230,11 +235,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
   } else {
-    gen_addresses(0);
-    load_tile();
-    store_tile();
+    if (kt0 < nkt) { gen_addresses(kt0); load_tile(); store_tile(); }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
       if (kt + 1 < nkt) { gen_addresses(kt + 1); load_tile(); }
       compute_tile(ldsA, ldsB);
       __syncthreads();
@@ -247,6 +250,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
   // ---------------------------------------- epilogue --------------------------------------------------
   // acc[i][j][e] = D[row = wm*TM*16 + i*16 + fq*4 + e][col = wn*TN*16 + j*16 + fr]
+  if (p.splitK > 1) {     // raw partial sums; bias / addend / ReLU / store happen in splitk_reduce_kernel
+    float* __restrict__ wsp = p.ws + (size_t)split * p.M * p.dC;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (TN * 16) + j * 16 + fr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
+          if (m < p.M && col < p.dC) wsp[(size_t)m * p.dC + col] = acc[i][j][e];
+        }
+      }
+    return;
+  }
   T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
   const T* __restrict__ addend = reinterpret_cast<const T*>(p.addend);
   constexpr int WCOLS = TN * 16;               // columns owned by a wave
@@ -352,6 +370,61 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   }
 }
 
+// Sum the split-K partials and apply the epilogue the conv kernel skipped: bias, residual addend, ReLU, store as T.
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int chunks = p.dC / VEC;                       // dC is a multiple of VEC (checked on the host)
+  const long long total = (long long)p.M * chunks;
+  T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
+  const T* __restrict__ addend = reinterpret_cast<const T*>(p.addend);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int m = (int)(idx / chunks), col = (int)(idx - (long long)m * chunks) * VEC;
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = p.bias ? p.bias[col + e] : 0.f;
+    for (int s = 0; s < p.splitK; ++s) {
+      const float* src = p.ws + ((size_t)s * p.M + m) * p.dC + col;
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src + e);
+        v[e] += t.x; v[e + 1] += t.y; v[e + 2] += t.z; v[e + 3] += t.w;
+      }
+    }
+    const size_t off = (size_t)m * (size_t)p.d_cs + (size_t)(p.d_co + col);
+    if (addend) {
+      Vec16<T> av; av.load(addend + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += av.get(e);
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    Vec16<T> ov;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ov.set(e, v[e]);
+    ov.store(dst + off);
+  }
+}
+
+// Per-device split-K workspace, allocated on first use (in the warm-up iterations, before any graph capture).
+static const size_t kSplitWsBytes = 64ull << 20;
+static float* splitk_workspace() {
+  static std::mutex mu;
+  static std::map<int, float*> ws;
+  std::lock_guard<std::mutex> lk(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto it = ws.find(dev);
+  if (it == ws.end()) {
+    float* ptr = nullptr;
+    if (hipMalloc((void**)&ptr, kSplitWsBytes) != hipSuccess) ptr = nullptr;
+    it = ws.emplace(dev, ptr).first;
+  }
+  return it->second;
+}
+
 template <typename T, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   ConvParams p = pin;
@@ -369,13 +442,36 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   size_t lds = (size_t)(BM + BN) * 128 * (use_glds ? 2 : 1);
   size_t epi = (size_t)(4 * 16 * (TN * 16 + 4) + WM * 2 * BN) * 4;
   if (epi > lds) lds = epi;
-  dim3 grid(p.tilesM * p.tilesN), block(256);
+  // Split-K for skinny problems (Linear layers: 64 x 9216 x 4096 has 64 tiles for 256 CUs): every split streams its
+  // share of the weights, raw partial sums go to a workspace and a small kernel finishes the epilogue.
+  static const int allow_split = [] { const char* e = getenv("DPA_CONV_SPLITK"); return (e && e[0] == '0') ? 0 : 1; }();
+  const int ntiles = p.tilesM * p.tilesN;
+  p.splitK = 1; p.kt_per_split = nkt; p.ws = nullptr;
+  if (allow_split && !p.stats && p.sh == 1 && p.sw == 1 && p.m_off == 0 && ntiles * 2 <= 256 && nkt >= 32 &&
+      (long long)p.Kg * p.dC >= (1 << 20)) {      // enough weight traffic to pay for the second launch
+    int want = (512 + ntiles - 1) / ntiles;
+    if (want > nkt / 8) want = nkt / 8;
+    const size_t need = (size_t)p.M * p.dC * sizeof(float);
+    while (want > 1 && need * want > kSplitWsBytes) --want;
+    float* ws = want > 1 ? splitk_workspace() : nullptr;
+    if (ws) {
+      p.kt_per_split = (nkt + want - 1) / want;
+      p.splitK = (nkt + p.kt_per_split - 1) / p.kt_per_split;
+      p.ws = ws;
+    }
+  }
+  dim3 grid(ntiles * p.splitK), block(256);
   if (use_glds) {     // LDS-DMA staging, double-buffered (default)
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true>), grid, block, lds, s, p);
   } else {            // register staging, single buffer (DPA_CONV_STAGING=reg: A/B reference)
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false>), grid, block, lds, s, p);
+  }
+  if (p.splitK > 1) {
+    const long long work = (long long)p.M * (p.dC / (16 / (int)sizeof(T)));
+    const int rb = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, s, p);
   }
 }
 

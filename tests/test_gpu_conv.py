@@ -93,3 +93,28 @@ def test_conv_channel_slice_and_epilogue():
     ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), bias=b, padding=1).permute(0, 2, 3, 1) + add
     torch.testing.assert_close(y, ref.clamp_min(0), rtol=1e-4, atol=1e-4)
     assert buf_out[..., :32].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_splitk_skinny_gemm(dtype):
+    """Linear-shaped problems (few output tiles, long reduction) take the split-K path: partial sums in a workspace,
+    bias + addend + ReLU in the reduce kernel.  Compared with the same op forced through the single-pass kernel's
+    reference (plain fp32 matmul)."""
+    from distributedpytorch_amd.ops import hip_conv
+    g = torch.Generator(device="cuda").manual_seed(11)
+    N, K, C = 64, 4608, 520                      # 520 outputs: not a multiple of the 64-wide tile
+    x = torch.randn(N, 1, 1, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(C, 1, 1, K, device="cuda", generator=g) * K ** -0.5).to(dtype)
+    b = torch.randn(C, device="cuda", generator=g)
+    add = torch.randn(N, 1, 1, C, device="cuda", generator=g).to(dtype)
+    y = torch.full((N, 1, 1, C), float("nan"), device="cuda", dtype=dtype)
+    hip_conv.conv_fprop(x, w, y, (1, 1), (0, 0), bias=b, relu=True, addend=add)
+    ref = (x.float().view(N, K) @ w.float().view(C, K).t() + b + add.float().view(N, C)).clamp_min(0)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(y.float().view(N, C), ref, **tol)
+    # dgrad of the same layer: dX[N, K] = dY[N, C] @ W[C, K]  (K outputs, reduction over C)
+    dy = torch.randn(N, 1, 1, C, device="cuda", generator=g).to(dtype)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    dx = torch.full((N, 1, 1, K), float("nan"), device="cuda", dtype=dtype)
+    hip_conv.conv_dgrad(dy, wt, dx, (1, 1), (0, 0))
+    torch.testing.assert_close(dx.float().view(N, K), dy.float().view(N, C) @ w.float().view(C, K), **tol)
