@@ -282,6 +282,12 @@ DPA_API void dpa_bn_stats(const void* x, int dtype, long long M, int C, int cs, 
   if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rpb);
   else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rpb);
 }
+// Same slab, caller-chosen row blocking (the split-K conv path rebuilds the stats its fused epilogue would have written).
+DPA_API void dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
+                               int nblocks, hipStream_t s) {
+  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rowsPerBlock);
+  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblocks), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rowsPerBlock);
+}
 DPA_API void dpa_bn_finalize(const float* slab, int rows, int C, long long count, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
                              float* mean_out, float* invstd_out, float* scale_out, float* shift_out, float* scratch,

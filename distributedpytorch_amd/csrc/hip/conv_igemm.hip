@@ -21,7 +21,7 @@
 // 64 zero bytes: the source of every padded / out-of-range 16-byte chunk of the LDS-DMA staging path
 __device__ uint4 dpa_zero_chunk[4];
 
-template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS>
+template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ntiles = p.tilesM * p.tilesN;
-  const int split = p.splitK > 1 ? (int)blockIdx.x / ntiles : 0;      // block-uniform
+  const int split = SPLIT ? (int)blockIdx.x / ntiles : 0;      // block-uniform (SPLIT kernels only run with splitK > 1)
   const int tile = xcd_remap((int)blockIdx.x - split * ntiles, ntiles);
   const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
   const int m0 = p.m_off + tm * BM, n0 = tn * BN;
@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt_all = (p.Kg + BKE - 1) / BKE;
-  const int kt0 = p.splitK > 1 ? split * p.kt_per_split : 0;
-  const int nkt = p.splitK > 1 ? min(nkt_all, kt0 + p.kt_per_split) : nkt_all;     // this block reduces K-tiles [kt0, nkt)
+  const int kt0 = SPLIT ? split * p.kt_per_split : 0;
+  const int nkt = SPLIT ? min(nkt_all, kt0 + p.kt_per_split) : nkt_all;     // this block reduces K-tiles [kt0, nkt)
   const int fr = lane & 15, fq = lane >> 4;
   auto compute_tile = [&](const char* tA, const char* tB) __attribute__((always_inline)) {
 #pragma unroll
@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     // compiler puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA (it cannot tell the two
     // buffers apart), which would wait for the prefetch right after issuing it and expose the whole global latency
     // every K-tile (measured: 63 % MFMA utilisation in fp32, profiles/README.md).
-    if (kt0 < nkt) { gen_addresses(kt0); issue_tile(0); }
+    gen_addresses(kt0);      // (splits are never empty; a zero-tap dgrad class has all loads predicated to the zero chunk)
+    issue_tile(0);
     for (int kt = kt0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -235,7 +236,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
   } else {
-    if (kt0 < nkt) { gen_addresses(kt0); load_tile(); store_tile(); }
+    gen_addresses(kt0);
+    load_tile();
+    store_tile();
     __syncthreads();
     for (int kt = kt0; kt < nkt; ++kt) {
       if (kt + 1 < nkt) { gen_addresses(kt + 1); load_tile(); }
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
   // ---------------------------------------- epilogue --------------------------------------------------
   // acc[i][j][e] = D[row = wm*TM*16 + i*16 + fq*4 + e][col = wn*TN*16 + j*16 + fr]
-  if (p.splitK > 1) {     // raw partial sums; bias / addend / ReLU / store happen in splitk_reduce_kernel
+  if constexpr (SPLIT) {     // raw partial sums; bias / addend / ReLU / store happen in splitk_reduce_kernel
     float* __restrict__ wsp = p.ws + (size_t)split * p.M * p.dC;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -370,6 +373,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   }
 }
 
+extern "C" void dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
+                                  int nblocks, hipStream_t s);
+
 // Sum the split-K partials and apply the epilogue the conv kernel skipped: bias, residual addend, ReLU, store as T.
 template <typename T>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p) {
@@ -447,9 +453,16 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   static const int allow_split = [] { const char* e = getenv("DPA_CONV_SPLITK"); return (e && e[0] == '0') ? 0 : 1; }();
   const int ntiles = p.tilesM * p.tilesN;
   p.splitK = 1; p.kt_per_split = nkt; p.ws = nullptr;
-  if (allow_split && !p.stats && p.sh == 1 && p.sw == 1 && p.m_off == 0 && ntiles * 2 <= 256 && nkt >= 32 &&
-      (long long)p.Kg * p.dC >= (1 << 20)) {      // enough weight traffic to pay for the second launch
-    int want = (512 + ntiles - 1) / ntiles;
+  constexpr int OCC = (BM * BN <= 64 * 64) ? 4 : (BM == 256 ? 1 : (BN <= 32 ? 3 : 2));     // resident blocks per CU
+  const int slots = 256 * OCC;
+  // Measured policy (scripts/bench_conv_layers.py --batch 64, scripts/bench_zoo.py): Linear-shaped problems (a few
+  // hundred rows) always gain; small-spatial convs gain only with a long reduction (K >= 4096), and when the BN
+  // statistics have to be rebuilt from the output afterwards only in bf16 (in fp32 that extra pass eats the gain).
+  const bool linear_like = p.M <= 256 && ntiles * 2 <= 256 && nkt >= 32;
+  const bool deep_conv = p.Kg >= 4096 && ntiles * 2 <= slots && (!p.stats || sizeof(T) == 2);
+  if (allow_split && p.sh == 1 && p.sw == 1 && p.m_off == 0 && (linear_like || deep_conv) &&
+      (long long)p.Kg * p.dC >= (1 << 20)) {      // enough weight traffic to pay for the extra launches
+    int want = slots / ntiles;
     if (want > nkt / 8) want = nkt / 8;
     const size_t need = (size_t)p.M * p.dC * sizeof(float);
     while (want > 1 && need * want > kSplitWsBytes) --want;
@@ -460,8 +473,13 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
       p.ws = ws;
     }
   }
+  if (p.splitK > 1 && lds < (size_t)(BM + BN) * 128 * 2) lds = (size_t)(BM + BN) * 128 * 2;   // split kernels use LDS-DMA staging
   dim3 grid(ntiles * p.splitK), block(256);
-  if (use_glds) {     // LDS-DMA staging, double-buffered (default)
+  if (p.splitK > 1) {   // split-K (always a long reduction, hence LDS-DMA staging); a separate instantiation so the
+                        // single-pass kernels keep their register allocation
+    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, true>), grid, block, lds, s, p);
+    else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true>), grid, block, lds, s, p);
+  } else if (use_glds) {     // LDS-DMA staging, double-buffered (default)
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true>), grid, block, lds, s, p);
   } else {            // register staging, single buffer (DPA_CONV_STAGING=reg: A/B reference)
@@ -472,9 +490,16 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
     const long long work = (long long)p.M * (p.dC / (16 / (int)sizeof(T)));
     const int rb = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, s, p);
+    if (p.stats)      // the fused-epilogue statistics, rebuilt from the stored output (one slab row per M-tile)
+      dpa_bn_stats_rows(reinterpret_cast<const T*>(p.dst) + p.d_co, sizeof(T) == 2 ? 1 : 0, p.M, p.dC, p.d_cs, p.stats, BM,
+                        p.tilesM, s);
   }
 }
 
+static int big_min() {      // fewest 128 x 128 tiles for which the big-tile config is chosen (smaller problems: 64 x 64)
+  static const int v = [] { const char* e = getenv("DPA_CONV_BIGMIN"); return e ? atoi(e) : 384; }();
+  return v;
+}
 static int tile_override() {
   static const int v = [] { const char* e = getenv("DPA_CONV_TILE"); return e ? atoi(e) : 0; }();
   return v;
@@ -513,7 +538,7 @@ static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
     else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
   } else if (tile_override() == 64)   launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);
   else if (tile_override() == 12864)  launch_cfg<T, 2, 2, 4, 2>(p, dgrad, s);   // 128 x 64
-  else if (big_tiles >= 384) {
+  else if (big_tiles >= big_min()) {
     // 128 x 128 tiles run in rounds of 512 (2 per CU); a nearly empty last round costs a full round.  Give whole
     // rounds to the big tiles and the few remaining rows to a second launch of 64 x 64 tiles (quarter-size work
     // items that spread over the chip): e.g. 1568 tiles = 3.06 rounds -> 3 rounds + a short tail instead of 4.
@@ -575,7 +600,7 @@ DPA_API int dpa_conv_stats_rows(int M, int dC) {
   if (dC <= 64) return ((M + 255) / 256 >= 256) ? (M + 255) / 256 : (M + 63) / 64;
   if (tile_override() == 64) return (M + 63) / 64;
   if (tile_override() == 12864) return (M + 127) / 128;
-  if (big_tiles >= 384) {
+  if (big_tiles >= big_min()) {
     const int split = tail_split_rows(M, dC);
     return split > 0 ? split / 128 + (M - split + 63) / 64 : (M + 127) / 128;
   }
