@@ -48,7 +48,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int bid = blockIdx.x;
+  // XCD-aware order: blocks that share an XCD (blockIdx % 8) get a contiguous run of the split-major work list, i.e.
+  // one or two pixel ranges, so each XCD's L2 streams 1/8 of dy and x instead of all of it (8 x less HBM/MALL traffic:
+  // the 3x3 layers had a 39 % L2 miss rate, profiles/r1_pmc_wgrad_14x14_256_3x3_fp32.txt)
+  // Measured per layer (scripts/bench_conv_layers.py): bf16 gains up to 25 % (net -7 % wgrad time); the MFMA-bound
+  // fp32 kernel gains 2-4 % on 1x1 layers but loses 10-15 % on 3x3 layers (every block of an XCD then hammers the same
+  // few L2 lines at the same time), so fp32 keeps the interleaved order there.
+  const bool xcd_order = sizeof(T) == 2 || p.R * p.S == 1;
+  int bid = xcd_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tilesMN = p.tilesM * p.tilesN;
   const int z = bid / tilesMN;
   bid -= z * tilesMN;
