@@ -22,6 +22,14 @@ DEBUG = _env("DEBUG", False, bool)
 DDTNodes = [
   {'address': '127.0.0.1', 'gpus': _env("GPUS", 'auto')},
 ]
+# DPA_DDT_NODES="addr:gpus;addr:gpus" overrides the list without editing this file, e.g.
+#   DPA_DDT_NODES="172.16.12.8:0,1;172.16.12.7:0,1"       (the reference's 2-node example)
+# DPA_NODE_ADDR=<address> tells the launcher which entry is this host when its interfaces do not show the listed
+# address (NAT, containers) or when several "nodes" are emulated on one machine.
+if _os.environ.get("DPA_DDT_NODES"):
+    DDTNodes = [{'address': e.split(':', 1)[0], 'gpus': (e.split(':', 1)[1] if ':' in e else 'auto')}
+                for e in _os.environ["DPA_DDT_NODES"].split(';') if e]
+NODE_ADDR = _env("NODE_ADDR", '')
 # two nodes, two GPUs each (the reference's example):
 # DDTNodes=[ {'address':'172.16.12.8', 'gpus':'0,1'}, {'address':'172.16.12.7', 'gpus':'0,1'} ]
 

@@ -72,7 +72,11 @@ def _gpu_list(spec):
 def getDDTInfo(nodes=None, local_ips=None):
     """(this node's GPU list as CSV, firstLocalRank, worldSize) from DDTNodes, like main.getDDTInfo."""
     nodes = _cfg().DDTNodes if nodes is None else nodes
-    ips = set((getLocalInterfaces() if local_ips is None else local_ips).values())
+    forced = getattr(_cfg(), "NODE_ADDR", "")
+    if local_ips is None and forced:
+        ips = {forced}
+    else:
+        ips = set((getLocalInterfaces() if local_ips is None else local_ips).values())
     node = None
     worldSize = 0
     firstLocalRank = 0

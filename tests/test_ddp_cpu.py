@@ -164,3 +164,32 @@ def test_cli_fault_injection_tears_down_all_ranks(tmp_path, tiny_data):
                  {"DPA_FAULT_INJECT": "1:1", "DPA_COLLECTIVE_TIMEOUT_S": "30"}, timeout=300)
     assert r.returncode != 0
     assert "fault injection: rank 1" in r.stdout + r.stderr
+
+
+def test_cli_two_nodes_two_launchers(tmp_path, tiny_data):
+    """Multi-node process model of the reference (README: 'run the same command on every node of DDTNodes'): two
+    launcher invocations emulate two hosts (127.0.0.1 and 127.0.0.2, one CPU rank each); ranks come from the node
+    order, rendezvous goes through the C++ store and gloo, and only global rank 0 writes the checkpoint."""
+    port = str(_free_port())
+    common = dict(os.environ, DPA_MODEL_NAME="basic", DPA_DDT_NODES="127.0.0.1:0;127.0.0.2:0", DPA_MASTER_ADDR="127.0.0.1",
+                  DPA_MASTER_PORT=port, DPA_NUM_THREADS="2", PYTHONPATH=ROOT)
+    procs = []
+    for i, addr in enumerate(("127.0.0.1", "127.0.0.2")):
+        wd = tmp_path / f"node{i}"
+        wd.mkdir()
+        env = dict(common, DPA_NODE_ADDR=addr)
+        procs.append((wd, subprocess.Popen([sys.executable, os.path.join(ROOT, "main.py"), "train", "-d", tiny_data, "-e", "1",
+                                            "-b", "50", "--debug"], cwd=wd, env=env, stdout=subprocess.PIPE,
+                                           stderr=subprocess.STDOUT, text=True)))
+    outs = []
+    for wd, p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+        assert p.returncode == 0, out[-3000:]
+    assert "overall rank: 0, world size: 2" in outs[0] and "overall rank: 1, world size: 2" in outs[1]
+    assert (tmp_path / "node0" / "rsl" / "checkpoint-mnist-basic-000.pt.tar").exists()
+    assert not (tmp_path / "node1" / "rsl" / "checkpoint-mnist-basic-000.pt.tar").exists()
