@@ -148,7 +148,12 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(T* __restrict__ dy, int dy_cs, const T* __restrict__ y, int y_cs,
                                                             const T* __restrict__ x, int x_cs, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, long long M, int C,
-                                                            float* __restrict__ slab, int rowsPerBlock) {
+                                                            float* __restrict__ slab, int rowsPerBlock,
+                                                            const float* __restrict__ mscale,
+                                                            const float* __restrict__ mshift) {
+  // ReLU mask: from `y` (dy is then masked IN PLACE for bn_bwd_dx and the residual branch), or - for BN+ReLU without a
+  // residual - recomputed as scale*x+shift > 0 from the x this kernel reads anyway (mscale/mshift = the forward's
+  // folded coefficients): no y read and no dy write, 2 of the 7 memory passes of the BN backward.
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[2][256][VEC > 4 ? 9 : 5];
   const int cpr = C / VEC;
@@ -159,17 +164,24 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(T* __restrict__ dy, 
   const long long r0 = (long long)blockIdx.x * rowsPerBlock;
   long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
   for (int cb = 0; cb < cpr; cb += colsPerPass) {
-    float s[VEC], q[VEC], mu[VEC], is[VEC];
+    float s[VEC], q[VEC], mu[VEC], is[VEC], msc[VEC], msh[VEC];
     const int cc = cb + col;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; msc[e] = 0.f; msh[e] = 1.f; }
     if (cc < cpr && rl < rowLanes) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { mu[e] = mean[cc * VEC + e]; is[e] = invstd[cc * VEC + e]; }
+      if (mscale) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { msc[e] = mscale[cc * VEC + e]; msh[e] = mshift[cc * VEC + e]; }
+      }
       for (long long r = r0 + rl; r < r1; r += rowLanes) {
         Vec16<T> g; g.load(dy + r * dy_cs + (long long)cc * VEC);
         Vec16<T> xv; xv.load(x + r * x_cs + (long long)cc * VEC);
-        if (y) {
+        if (mscale) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) if (!(xv.get(e) * msc[e] + msh[e] > 0.f)) g.set(e, 0.f);
+        } else if (y) {
           Vec16<T> yv; yv.load(y + r * y_cs + (long long)cc * VEC);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) if (!(yv.get(e) > 0.f)) g.set(e, 0.f);
@@ -221,7 +233,9 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __rest
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz, int dz_cs, const T* x, int x_cs,
                                                         const float* __restrict__ coef, T* dx, int dx_cs,
-                                                        long long M, int C, int rowsPerBlock) {
+                                                        long long M, int C, int rowsPerBlock,
+                                                        const float* __restrict__ mscale,
+                                                        const float* __restrict__ mshift) {
   constexpr int VEC = 16 / sizeof(T);
   const int cpr = C / VEC;
   const int colsPerPass = cpr < 256 ? cpr : 256;
@@ -242,12 +256,19 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
       B[e] = b.x; B[e + 1] = b.y; B[e + 2] = b.z; B[e + 3] = b.w;
       D[e] = d.x; D[e + 1] = d.y; D[e + 2] = d.z; D[e + 3] = d.w;
     }
+    float msc[VEC], msh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { msc[e] = mscale ? mscale[c + e] : 0.f; msh[e] = mscale ? mshift[c + e] : 1.f; }
     for (long long m = r0 + rl; m < r1; m += rowLanes) {
       Vec16<T> g; g.load(dz + m * dz_cs + c);
       Vec16<T> xv; xv.load(x + m * x_cs + c);   // dx may alias x: each thread reads its chunk before writing it
       Vec16<T> o;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o.set(e, A[e] * g.get(e) + B[e] * xv.get(e) + D[e]);
+      for (int e = 0; e < VEC; ++e) {
+        const float xe = xv.get(e);
+        const float ge = (xe * msc[e] + msh[e] > 0.f) ? g.get(e) : 0.f;      // (no mask: 0*x + 1 > 0 always)
+        o.set(e, A[e] * ge + B[e] * xe + D[e]);
+      }
       o.store(dx + m * dx_cs + c);
     }
   }
@@ -312,24 +333,24 @@ DPA_API void dpa_bn_apply(const void* x, int x_cs, const float* scale, const flo
 DPA_API void dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, const void* x, int x_cs, const float* mean,
                                const float* invstd, const float* gamma, long long M, int C, float* slab, float* scratch,
                                float* dgamma, float* dbeta, float* sums, float* coef, int accumulate, int dtype,
-                               hipStream_t s) {
+                               hipStream_t s, const float* mscale, const float* mshift) {
   int nb; const int rpb = rows_per_block(M, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (bf16_t*)dy, dy_cs, (const bf16_t*)y,
-                                     y_cs, (const bf16_t*)x, x_cs, mean, invstd, M, C, slab, rpb);
+                                     y_cs, (const bf16_t*)x, x_cs, mean, invstd, M, C, slab, rpb, mscale, mshift);
   else            hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, s, (float*)dy, dy_cs, (const float*)y,
-                                     y_cs, (const float*)x, x_cs, mean, invstd, M, C, slab, rpb);
+                                     y_cs, (const float*)x, x_cs, mean, invstd, M, C, slab, rpb, mscale, mshift);
   int rows = nb;
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
                      mean, invstd, gamma, 1.0f / (float)M, coef);
 }
 DPA_API void dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
-                           long long M, int C, int dtype, hipStream_t s) {
+                           long long M, int C, int dtype, hipStream_t s, const float* mscale, const float* mshift) {
   int nb; const int rpb = ew_rows_per_block(M, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
-                                     (const bf16_t*)x, x_cs, coef, (bf16_t*)dx, dx_cs, M, C, rpb);
+                                     (const bf16_t*)x, x_cs, coef, (bf16_t*)dx, dx_cs, M, C, rpb, mscale, mshift);
   else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, dz_cs,
-                                     (const float*)x, x_cs, coef, (float*)dx, dx_cs, M, C, rpb);
+                                     (const float*)x, x_cs, coef, (float*)dx, dx_cs, M, C, rpb, mscale, mshift);
 }
 
 // Per-channel column sum of a tall activation (conv bias gradients): stats slab -> fixed-order reduce.

@@ -205,17 +205,21 @@ class BatchNorm2d:
                                a[2], a[3])
         return a
 
-    def backward(self, ctx: Context, dy, y_for_mask, z, dx_out):
-        """dz = dy*(y>0) in place; dgamma/dbeta -> arena; returns dx (written into dx_out)."""
+    def backward(self, ctx: Context, dy, y_for_mask, z, dx_out, mask_from_x=False):
+        """dz = dy*(y>0) in place; dgamma/dbeta -> arena; returns dx (written into dx_out).  mask_from_x (BN+ReLU with no
+        residual, nobody else needs the masked dy): the mask is recomputed from z with the forward's folded
+        coefficients a[2], a[3] - y is not read and dy is not rewritten."""
         st = self.store
         a = self.aux(ctx.device)
         dg = st.gview(self.gamma) if self.trainable else None
         db = st.gview(self.beta) if self.trainable else None
-        ops.bn_bwd_reduce(dy, y_for_mask, z, a[0], a[1], st.view(self.gamma), dg, db, a[4:6], a[6:9])
+        ms, mh = (a[2], a[3]) if mask_from_x else (None, None)
+        ops.bn_bwd_reduce(dy, None if mask_from_x else y_for_mask, z, a[0], a[1], st.view(self.gamma), dg, db, a[4:6], a[6:9],
+                          mask_scale=ms, mask_shift=mh)
         if self.trainable:
             ctx.tape.ready(self.gamma)
             ctx.tape.ready(self.beta)
-        ops.bn_bwd_dx(dy, z, a[6:9], dx_out)
+        ops.bn_bwd_dx(dy, z, a[6:9], dx_out, mask_scale=ms, mask_shift=mh)
         return dx_out
 
 
@@ -247,7 +251,8 @@ class ConvBNAct:
             def bw():
                 dy = y.grad
                 y.grad = None
-                dz = bn.backward(ctx, dy, y.data if relu else None, z, z)   # dx overwrites z (dead after this)
+                dz = bn.backward(ctx, dy, y.data if relu else None, z, z,   # dx overwrites z (dead after this)
+                                 mask_from_x=relu and residual is None and ctx.training)
                 if residual is not None and residual.needs_grad:
                     accumulate_grad(residual, dy)                            # dy now holds dy*(y>0)
                 conv.backward_raw(ctx, x, dz)
@@ -280,7 +285,7 @@ class BNAct:
                 dy = y.grad
                 y.grad = None
                 dx = ctx.empty((n, h, w, c))
-                bn.backward(ctx, dy, y.data if relu else None, x.data, dx)
+                bn.backward(ctx, dy, y.data if relu else None, x.data, dx, mask_from_x=relu and ctx.training)
                 if x.needs_grad:
                     accumulate_grad(x, dx)
             ctx.tape.push(bw)

@@ -93,7 +93,8 @@ def bn_apply(x, scale, shift, y, residual=None, relu=False):
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab=None, scratch=None, accumulate=False):
+def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab=None, scratch=None, accumulate=False,
+                  mask_scale=None, mask_shift=None):
     m, c, dcs = _mc(dy)
     xcs = _mc(x)[2]
     ycs = _mc(y)[2] if y is not None else 0
@@ -104,13 +105,13 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab
         scratch = _scratch_f32(dy.device, ROWS_L2 * 2 * c, "bn")
     _lib().dpa_bn_bwd_reduce(ptr(dy), dcs, ptr(y), ycs, ptr(x), xcs, ptr(mean), ptr(invstd), ptr(gamma), I64(m), c,
                              ptr(slab), ptr(scratch), ptr(dgamma), ptr(dbeta), ptr(sums), ptr(coef), int(accumulate),
-                             _DT[dy.dtype], stream_ptr())
+                             _DT[dy.dtype], stream_ptr(), ptr(mask_scale), ptr(mask_shift))
 
 
-def bn_bwd_dx(dz, x, coef, dx):
+def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None):
     m, c, zcs = _mc(dz)
     _lib().dpa_bn_bwd_dx(ptr(dz), zcs, ptr(x), _mc(x)[2], ptr(coef), ptr(dx), _mc(dx)[2], I64(m), c, _DT[dz.dtype],
-                         stream_ptr())
+                         stream_ptr(), ptr(mask_scale), ptr(mask_shift))
     return dx
 
 

@@ -131,12 +131,18 @@ def bn_apply(x, scale, shift, y, residual=None, relu=False):
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab=None, scratch=None, accumulate=False):
+def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab=None, scratch=None, accumulate=False,
+                  mask_scale=None, mask_shift=None):
     """Masks dy in place by (y > 0) when y is given; sums[0]=sum dz, sums[1]=sum dz*xhat; dgamma/dbeta; coef = the
-    folded per-channel (A, B, D) of dx = A*dz + B*x + D consumed by bn_bwd_dx."""
-    if y is not None:
-        dy.mul_((y > 0).to(dy.dtype))
-    dz = dy.float().reshape(-1, dy.shape[-1])
+    folded per-channel (A, B, D) of dx = A*dz + B*x + D consumed by bn_bwd_dx.  With mask_scale/mask_shift the ReLU mask
+    is recomputed as scale*x+shift > 0 and dy is left untouched (bn_bwd_dx gets the same coefficients)."""
+    if mask_scale is not None:
+        dz = dy.float() * ((x.float() * mask_scale + mask_shift) > 0)
+        dz = dz.reshape(-1, dy.shape[-1])
+    else:
+        if y is not None:
+            dy.mul_((y > 0).to(dy.dtype))
+        dz = dy.float().reshape(-1, dy.shape[-1])
     m = dz.shape[0]
     xh = (x.float().reshape(-1, x.shape[-1]) - mean) * invstd
     s = dz.sum(0)
@@ -161,8 +167,11 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab
     coef[2].copy_(-a * s / m - b * mean)
 
 
-def bn_bwd_dx(dz, x, coef, dx):
-    out = coef[0] * dz.float() + coef[1] * x.float() + coef[2]
+def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None):
+    g = dz.float()
+    if mask_scale is not None:
+        g = g * ((x.float() * mask_scale + mask_shift) > 0)
+    out = coef[0] * g + coef[1] * x.float() + coef[2]
     dx.copy_(out.to(dx.dtype))
     return dx
 

@@ -55,6 +55,40 @@ def test_bn_forward_backward(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_backward_mask_recomputed_from_x(dtype):
+    """BN+ReLU without a residual: the ReLU mask recomputed from x with the forward's folded coefficients must give the
+    same dgamma / dbeta / dx as the stored-output mask, and must leave dy untouched."""
+    from distributedpytorch_amd.ops import hip_ops as H
+    shape = (4, 9, 11, 72)
+    c, m = shape[3], shape[0] * shape[1] * shape[2]
+    x = (_rand(shape, dtype, 1, 2.0) + 0.3).cuda()
+    g, b = (torch.rand(c) + 0.5).cuda(), torch.randn(c).cuda()
+    rm, rv, nbt = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    slab = torch.zeros(H.bn_slab_rows(m), 2, c, device="cuda")
+    H.bn_stats(x, slab)
+    mean, invstd, scale, shift = (torch.zeros(c, device="cuda") for _ in range(4))
+    H.bn_finalize(slab, m, g, b, rm, rv, nbt, 0.1, 1e-5, mean, invstd, scale, shift)
+    y = torch.empty_like(x)
+    H.bn_apply(x, scale, shift, y, relu=True)
+    dy0 = _rand(shape, dtype, 3).cuda()
+    res = []
+    for from_x in (False, True):
+        dy = dy0.clone()
+        dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        sums, coef = torch.zeros(2, c, device="cuda"), torch.zeros(3, c, device="cuda")
+        kw = dict(mask_scale=scale, mask_shift=shift) if from_x else {}
+        H.bn_bwd_reduce(dy, None if from_x else y, x, mean, invstd, g, dg, db, sums, coef, **kw)
+        dx = torch.empty_like(x)
+        H.bn_bwd_dx(dy, x, coef, dx, **kw)
+        res.append((dg.clone(), db.clone(), dx.float().clone(), dy.clone()))
+    assert torch.equal(res[1][3], dy0)                       # dy untouched in the recompute mode
+    assert not torch.equal(res[0][3], dy0)                   # masked in place in the stored-output mode
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    for a_, b_ in zip(res[0][:3], res[1][:3]):
+        torch.testing.assert_close(a_, b_, **tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_bn_eval_and_channel_slices(dtype):
     from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
     buf = _rand((2, 6, 6, 64), dtype, 5)
