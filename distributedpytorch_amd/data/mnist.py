@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..nn.engine import pad_to
+from ..nn.engine import input_pad, pad_to
 from ..ops import native
 from .sampler import DistributedSampler
 
@@ -146,7 +146,7 @@ class MNIST:
         self.device = device if device is not None else torch.device("cuda", gpu) if gpu >= 0 else torch.device("cpu")
         self.dtype, self.debug, self.seed = dtype, debug, seed
         self.nbClasses = 10
-        self.cpad = pad_to(3)
+        self.cpad = input_pad(3, dtype)
         self.data = {"train": None, "valid": None, "test": None}
         self.sampler = {"train": None, "valid": None, "test": None}
         self.iterator = {"train": None, "valid": None, "test": None}

@@ -7,7 +7,7 @@ import logging
 
 import torch
 
-from ..nn.engine import Act, Context, ParamStore, Tape, pad_to
+from ..nn.engine import Act, Context, ParamStore, Tape, input_pad, pad_to
 
 MODEL_NAMES = ("resnet", "alexnet", "vgg", "squeezenet", "densenet", "inception", "resnet50", "basic")
 
@@ -40,7 +40,7 @@ class Network:
 
     @property
     def in_channels(self):
-        return pad_to(getattr(self.net, "in_channels", 3))
+        return input_pad(getattr(self.net, "in_channels", 3), self.store.compute_dtype)
 
     def forward(self, x: torch.Tensor, tape: Tape = None):
         """x: NHWC activation in the compute dtype with channels padded to `in_channels`."""

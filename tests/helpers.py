@@ -2,13 +2,13 @@
 import torch
 import torch.nn.functional as F
 
-from distributedpytorch_amd.nn.engine import Tape, pad_to
+from distributedpytorch_amd.nn.engine import Tape, input_pad, pad_to
 from distributedpytorch_amd.nn.loss import Criterion
 
 
 def to_nhwc_padded(x_nchw, dtype, device):
     n, c, h, w = x_nchw.shape
-    out = torch.zeros(n, h, w, pad_to(c), dtype=dtype, device=device)
+    out = torch.zeros(n, h, w, input_pad(c, dtype), dtype=dtype, device=device)
     out[..., :c] = x_nchw.permute(0, 2, 3, 1).to(device=device, dtype=dtype)
     return out
 

@@ -116,7 +116,7 @@ def test_mnist_split_sizes_stats_and_determinism(small_mnist):
     ib = b.sampler["train"].indices().tolist()
     assert len(ia) == 270 and not set(ia) & set(ib)
     x, y = next(iter(a.iterator["train"]))
-    assert x.shape == (32, 28, 28, 8) and y.shape == (32,) and x[..., 3:].abs().max() == 0
+    assert x.shape == (32, 28, 28, 4) and y.shape == (32,) and x[..., 3:].abs().max() == 0   # fp32: 3 -> 4 channels
     x2, _ = next(iter(a.iterator["train"]))
     assert torch.equal(x, x2)                                                       # seeded augmentation
     a.sampler["train"].set_epoch(1)
