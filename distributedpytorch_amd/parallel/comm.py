@@ -15,7 +15,7 @@ import torch.distributed as dist
 def warm_kernel_library(device):
     """Load the gfx950 code object (one trivial launch + sync) before any RCCL communicator exists: on the ROCm 7.0
     runtime a module first loaded AFTER ncclCommInitRank deadlocked later cross-stream event waits (measured with the
-    native communicator, scripts/dbg_rccl5.py vs dbg_rccl6.py); loading it first costs ~ms once."""
+    native communicator, scripts/debug/dbg_rccl5.py vs dbg_rccl6.py); loading it first costs ~ms once."""
     from .. import ops
     warm = torch.zeros(2, dtype=torch.int64, device=device)
     ops.rng_advance(warm)

@@ -38,7 +38,7 @@ class NativeRcclComm:
         self.rank, self.world = rank, world
         # Load the kernel library's code object BEFORE ncclCommInitRank.  Measured on MI355X (ROCm 7.0 runtime):
         # when the gfx950 module is first loaded after the communicator exists, later cross-stream event waits
-        # deadlock (scripts/dbg_rccl5.py hangs, dbg_rccl6.py - same steps, comm created after a warm step - passes).
+        # deadlock (scripts/debug/dbg_rccl5.py hangs, dbg_rccl6.py - same steps, comm created after a warm step - passes).
         from .comm import warm_kernel_library
         warm_kernel_library(torch.device("cuda", device_index))
         n = self.lib.dpa_comm_unique_id_size()

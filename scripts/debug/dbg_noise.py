@@ -1,5 +1,5 @@
 import sys, copy, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from distributedpytorch_amd.models.factory import get_model
 from tests import torch_ref_models as ref
 from tests.helpers import framework_step, grads_by_name, oracle_step
