@@ -93,6 +93,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    peak_gb = []
+
     def measure(dtype_name):
         """Build the model in `dtype_name`, run warmup + EXACTLY args.steps timed full training iterations."""
         torch.manual_seed(1234)
@@ -125,6 +127,7 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
         loss, _, _ = dm.epoch_metrics()
+        peak_gb.append(round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1))
         del dm, opt, net, x, y
         torch.cuda.empty_cache()
         return elapsed, loss, use_graph
@@ -156,7 +159,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, device-resident batch)",
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch, "seq_len": None,
                        "image": f"{side}x{side}x3", "classes": classes, "optimizer": args.optimizer,
-                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "comm": args.comm, "hipgraph": use_graph,
+                       "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "comm": args.comm,
+                       "peak_hbm_gb": peak_gb[0] if peak_gb else None, "hipgraph": use_graph,
                        "mean_loss": round(loss, 4)},
             "secondary": secondary,
         }), flush=True)

@@ -1,0 +1,46 @@
+"""Static resource guard for the hot kernels (runs without a GPU: hipcc cross-compiles gfx950).
+
+A change elsewhere in a kernel can silently push the register allocation over the 256-register budget of two waves
+per SIMD, or into scratch - the first costs ~40 % on the affected layers, the second 2-3x (both happened during
+bring-up).  This test compiles the two convolution translation units to ISA and checks the compiler's own resource
+summary for every instantiation."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_DIR = os.path.join(ROOT, "distributedpytorch_amd", "csrc", "hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _resources(src, tmp_path):
+    out = tmp_path / (os.path.basename(src) + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-fno-gpu-rdc", "-DNDEBUG", "--cuda-device-only",
+           "-S", src, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=HIP_DIR)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res, name, info = {}, None, {}
+    for line in open(out):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            name, info = m.group(1), {}
+        for key in ("NumVgprs", "NumAgprs", "ScratchSize", "Occupancy"):
+            m2 = re.match(r"^; %s: (\d+)" % key, line)
+            if m2 and name:
+                info[key] = int(m2.group(1))
+        if name and line.startswith("; Occupancy"):
+            res[name] = info
+            name = None
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,kernel", [("conv_igemm.hip", "conv_igemm_kernel"), ("conv_wgrad.hip", "conv_wgrad_kernel")])
+def test_conv_kernels_fit_two_waves_per_simd_without_scratch(src, kernel, tmp_path):
+    res = {k: v for k, v in _resources(os.path.join(HIP_DIR, src), tmp_path).items() if kernel in k}
+    assert len(res) >= 8, f"expected the template instantiations of {kernel}, found {len(res)}"
+    bad = {k: v for k, v in res.items() if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < 2}
+    assert not bad, "kernels with scratch or < 2 waves/SIMD:\n" + "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
