@@ -248,7 +248,10 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   p.tilesN = (p.Ng + BN - 1) / BN;
   const int tiles = p.tilesM * p.tilesN;
   const int ksteps = (p.P + BKP - 1) / BKP;
-  int split = (512 + tiles - 1) / tiles;          // ~2 blocks per CU; slab traffic grows with the split
+  // At most 512 blocks = 2 per CU, all resident at once.  (Rounding UP here put every 3x3 layer at 513-576 blocks:
+  // a second, almost empty round that cost 20-25 % - PMC showed the same cycles per MFMA as the 1x1 layers but lower
+  // residency.)  Slab traffic grows with the split.
+  int split = 512 / tiles;
   if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
   if (!workspace) split = 1;
