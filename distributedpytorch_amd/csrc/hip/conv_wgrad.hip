@@ -51,9 +51,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
   // XCD-aware order: blocks that share an XCD (blockIdx % 8) get a contiguous run of the split-major work list, i.e.
   // one or two pixel ranges, so each XCD's L2 streams 1/8 of dy and x instead of all of it (8 x less HBM/MALL traffic:
   // the 3x3 layers had a 39 % L2 miss rate, profiles/r1_pmc_wgrad_14x14_256_3x3_fp32.txt)
-  // Measured per layer (scripts/bench_conv_layers.py): bf16 gains up to 25 % (net -7 % wgrad time); the MFMA-bound
-  // fp32 kernel gains 2-4 % on 1x1 layers but loses 10-15 % on 3x3 layers (every block of an XCD then hammers the same
-  // few L2 lines at the same time), so fp32 keeps the interleaved order there.
+  // Measured (scripts/bench_conv_layers.py, profiles/r1_pmc_wgrad_28x28_*): L2 hit rate 10 % -> 85 %, bf16 wgrad time
+  // -8 %; neutral for the MFMA-bound fp32 kernel.
   const bool xcd_order = (p.accumulate & 2) != 0;        // chosen on the host (wg_launch)
   int bid = xcd_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tilesMN = p.tilesM * p.tilesN;
@@ -261,7 +260,7 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   p.pixPerSplit = steps_per * BKP;
   // bit 1 of `accumulate`: XCD-contiguous block order (see the kernel).  DPA_WGRAD_XCD=0|1 overrides the measured default.
   static const int xcd_env = [] { const char* e = getenv("DPA_WGRAD_XCD"); return e ? atoi(e) : -1; }();
-  const bool xcd_order = xcd_env >= 0 ? xcd_env != 0 : (sizeof(T) == 2 || p.R * p.S == 1);
+  const bool xcd_order = xcd_env >= 0 ? xcd_env != 0 : true;
   p.accumulate = (p.accumulate & 1) | (xcd_order ? 2 : 0);
   p.out = split == 1 ? grad : workspace;
   size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
