@@ -22,7 +22,7 @@
 __device__ uint4 dpa_zero_chunk[4];
 
 template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
   constexpr int BKE = 8 * VEC;               // reduction elements per K-tile (128-byte rows)
