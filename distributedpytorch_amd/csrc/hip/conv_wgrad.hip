@@ -30,7 +30,7 @@ template <> struct WgLds<bf16_t> { static constexpr int PAD = 32; };   // bytes;
 template <> struct WgLds<float>  { static constexpr int PAD = 64; };   // (pitch/4) % 32 == 16
 
 template <typename T, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BKP = 8 * VEC;                          // pixels per K-tile (64 bf16 / 32 fp32)
@@ -247,10 +247,11 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   p.tilesN = (p.Ng + BN - 1) / BN;
   const int tiles = p.tilesM * p.tilesN;
   const int ksteps = (p.P + BKP - 1) / BKP;
-  // At most 512 blocks = 2 per CU, all resident at once.  (Rounding UP here put every 3x3 layer at 513-576 blocks:
+  // At most one resident round of blocks.  (Rounding UP here put every 3x3 layer at 513-576 blocks with 512 slots:
   // a second, almost empty round that cost 20-25 % - PMC showed the same cycles per MFMA as the 1x1 layers but lower
   // residency.)  Slab traffic grows with the split.
-  int split = 512 / tiles;
+  static const int target = [] { const char* e = getenv("DPA_WGRAD_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+  int split = target / tiles;       // 768 = 3 resident blocks per CU (the kernel is built for 3 waves/SIMD)
   if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
   if (!workspace) split = 1;
@@ -299,7 +300,7 @@ DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {
   const int bm = (Ng <= 64 || K <= 64) ? 64 : 128;
   const int bn = Ng <= 64 ? 64 : (K <= 64 ? ((Ng % 192 == 0 && Ng % 256 != 0) ? 192 : 256) : 128);
   const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bn - 1) / bn);
-  long long split = (512 + tiles - 1) / tiles;
+  long long split = (1024 + tiles - 1) / tiles;      // upper bound of what wg_launch may choose
   return split * (long long)K * Ng;
 }
 DPA_API int dpa_wgrad_params_size() { return (int)sizeof(WgradParams); }
