@@ -22,6 +22,7 @@ struct WgradParams {
   int Ng;            // R*S*C
   int tilesM, tilesN, splitK, pixPerSplit;
   int accumulate;    // splitK == 1 only: out += result
+  int xcd_order;     // XCD-contiguous block order (set by wg_launch)
   FastDiv fd_Wo, fd_Ho, fd_C, fd_S;
 };
 
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p)
   // the 3x3 layers had a 39 % L2 miss rate, profiles/r1_pmc_wgrad_14x14_256_3x3_fp32.txt)
   // Measured (scripts/bench_conv_layers.py, profiles/r1_pmc_wgrad_28x28_*): L2 hit rate 10 % -> 85 %, bf16 wgrad time
   // -8 %; neutral for the MFMA-bound fp32 kernel.
-  const bool xcd_order = (p.accumulate & 2) != 0;        // chosen on the host (wg_launch)
+  const bool xcd_order = p.xcd_order != 0;               // chosen on the host (wg_launch)
   int bid = xcd_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int tilesMN = p.tilesM * p.tilesN;
   const int z = bid / tilesMN;
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p)
         const int row = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
         if (row < p.K && col < p.Ng) {
           float* o = out + (size_t)row * p.Ng + col;
-          *o = ((p.accumulate & 1) && p.splitK == 1) ? (*o + acc[i][j][e]) : acc[i][j][e];
+          *o = (p.accumulate && p.splitK == 1) ? (*o + acc[i][j][e]) : acc[i][j][e];
         }
       }
     }
@@ -259,17 +260,17 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   split = (ksteps + steps_per - 1) / steps_per;
   p.splitK = split;
   p.pixPerSplit = steps_per * BKP;
-  // bit 1 of `accumulate`: XCD-contiguous block order (see the kernel).  DPA_WGRAD_XCD=0|1 overrides the measured default.
+  // XCD-contiguous block order (see the kernel).  DPA_WGRAD_XCD=0|1 overrides the measured default.
   static const int xcd_env = [] { const char* e = getenv("DPA_WGRAD_XCD"); return e ? atoi(e) : -1; }();
   const bool xcd_order = xcd_env >= 0 ? xcd_env != 0 : true;
-  p.accumulate = (p.accumulate & 1) | (xcd_order ? 2 : 0);
+  p.xcd_order = xcd_order ? 1 : 0;
   p.out = split == 1 ? grad : workspace;
   size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
   if (split > 1) {
     const long long n = (long long)p.K * p.Ng;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, workspace, grad, n,
-                       split, p.accumulate & 1);
+                       split, p.accumulate);
   }
 }
 

@@ -49,7 +49,7 @@ class WgradParams(ctypes.Structure):
         ("Ho", I32), ("Wo", I32), ("K", I32), ("k_cs", I32), ("k_co", I32),
         ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),
         ("P", I32), ("Ng", I32), ("tilesM", I32), ("tilesN", I32), ("splitK", I32), ("pixPerSplit", I32),
-        ("accumulate", I32),
+        ("accumulate", I32), ("xcd_order", I32),
         ("fd_Wo", FastDiv), ("fd_Ho", FastDiv), ("fd_C", FastDiv), ("fd_S", FastDiv),
     ]
 
