@@ -192,7 +192,7 @@ class GradReducer:
     # ------------------------------------------------------------------ diagnostics
     def check_in_sync(self):
         """All ranks must hold bit-identical parameters; returns the max deviation of the checksum (0.0 if in sync)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return 0.0
         cs = torch.stack([self.store.p.double().sum(), self.store.p.double().abs().sum()])
         lo, hi = cs.clone(), cs.clone()

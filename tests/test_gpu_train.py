@@ -132,3 +132,49 @@ def test_native_rccl_comm_world1_matches_plain():
         assert torch.equal(nets[0], nets[1])
     finally:
         comm.destroy()
+
+
+def test_torch_rccl_collectives_world1_match_plain():
+    """The default DDP backend on real hardware: a 1-rank RCCL process group with DPA_FORCE_COLLECTIVES=1 issues every
+    collective of the multi-GPU path (layout all-gather, wrap-time and per-step broadcasts, async bucket all-reduce,
+    wait + per-bucket optimizer).  Over one rank they are identities, so training must match the plain path bit for bit."""
+    script = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["DPA_ROOT"])
+from distributedpytorch_amd.models.factory import get_model
+from distributedpytorch_amd.nn.loss import Criterion
+from distributedpytorch_amd.nn.optim import ArenaOptimizer
+from distributedpytorch_amd.parallel import comm
+from distributedpytorch_amd.parallel.ddp import DistributedModel
+force = os.environ.get("DPA_FORCE_COLLECTIVES") == "1"
+torch.cuda.set_device(0)
+if force:
+    comm.init_process_group(0, 1, torch.device("cuda", 0), timeout_s=60)
+torch.manual_seed(0)
+net, _ = get_model("resnet", 10, device="cuda", dtype=torch.bfloat16)
+dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3), first_bucket_mb=0.25, bucket_cap_mb=4.0)
+assert dm.reducer.force == force and len(dm.reducer.buckets) > 4
+g = torch.Generator(device="cuda").manual_seed(3)
+x = torch.zeros(16, 64, 64, net.in_channels, device="cuda", dtype=torch.bfloat16)
+x[..., :3] = torch.randn(16, 64, 64, 3, device="cuda", generator=g).to(torch.bfloat16)
+y = torch.randint(0, 10, (16,), device="cuda", generator=g)
+for _ in range(3):
+    dm.train_step(x, y)
+torch.cuda.synchronize()
+torch.save(net.store.p.cpu(), sys.argv[1])
+if force:
+    assert dm.reducer.check_in_sync() == 0.0
+    comm.destroy_process_group()
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w1.py")
+        open(path, "w").write(script)
+        outs = []
+        for force in ("0", "1"):
+            out = os.path.join(d, f"p{force}.pt")
+            env = dict(os.environ, DPA_ROOT=ROOT, DPA_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+            r = subprocess.run([sys.executable, path, out], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            outs.append(torch.load(out))
+        assert torch.equal(outs[0], outs[1])
