@@ -81,4 +81,7 @@ RENDEZVOUS_TIMEOUT_S = _env("RENDEZVOUS_TIMEOUT_S", 300.0, float)
 COLLECTIVE_TIMEOUT_S = _env("COLLECTIVE_TIMEOUT_S", 600.0, float)
 CHECK_SYNC_EVERY = _env("CHECK_SYNC_EVERY", 0, int)   # >0: all-rank parameter checksum every N epochs
 SYNTHETIC_DATA = _env("SYNTHETIC_DATA", True, bool)  # generate a deterministic synthetic MNIST under -d when the IDX files are absent
+# RCCL/NCCL transport knobs for multi-node runs, exported by the launcher when set (the reference keeps a commented
+# NCCL_IB_DISABLE line, main.py:131): e.g. DPA_NCCL_ENV="NCCL_IB_DISABLE=1,NCCL_SOCKET_IFNAME=eth0"
+NCCL_ENV = _env("NCCL_ENV", '')
 FAULT_INJECT = _env("FAULT_INJECT", '')          # test hook "rank:step": that rank exits(17) at that global step

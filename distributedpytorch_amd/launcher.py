@@ -117,6 +117,10 @@ def main(argv=None):
     os.environ['MASTER_ADDR'] = str(cfg.MASTER_ADDR)
     os.environ['MASTER_PORT'] = str(cfg.MASTER_PORT)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for kv in str(getattr(cfg, "NCCL_ENV", "")).split(','):          # transport knobs for multi-node RCCL
+        if '=' in kv:
+            k, v = kv.split('=', 1)
+            os.environ[k.strip()] = v.strip()
     nprocs = len(args.gpus.split(','))
     if cuda:
         os.environ['HIP_VISIBLE_DEVICES'] = args.gpus
