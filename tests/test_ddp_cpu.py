@@ -193,3 +193,18 @@ def test_cli_two_nodes_two_launchers(tmp_path, tiny_data):
     assert "overall rank: 0, world size: 2" in outs[0] and "overall rank: 1, world size: 2" in outs[1]
     assert (tmp_path / "node0" / "rsl" / "checkpoint-mnist-basic-000.pt.tar").exists()
     assert not (tmp_path / "node1" / "rsl" / "checkpoint-mnist-basic-000.pt.tar").exists()
+
+
+@pytest.mark.parametrize("loss,opt", [("focal_loss", "SGD"), ("weighted_cross_entropy", "adam")])
+def test_cli_other_losses_and_sgd_steplr(tmp_path, tiny_data, loss, opt):
+    """The reference's dead branches made live (Q10): weighted CE / focal loss with dataset class weights, and
+    SGD(momentum .9) + StepLR(1, .1) stepped once per epoch (classif.py:106-131,168-169)."""
+    r = _run_cli(tmp_path, ["train", "-d", tiny_data, "-e", "2", "-b", "50", "--debug"], {"DPA_LOSS": loss, "DPA_OPTIMIZER": opt})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Epoch: 002" in r.stdout
+    ck = torch.load(tmp_path / "rsl" / "checkpoint-mnist-basic-001.pt.tar")
+    group = ck["optimizer_state_dict"]["param_groups"][0]
+    if opt == "SGD":
+        assert group["momentum"] == 0.9 and abs(group["lr"] - 1e-5) < 1e-12      # 1e-3 * 0.1 ** 2 after two epochs
+    else:
+        assert abs(group["lr"] - 1e-3) < 1e-12
