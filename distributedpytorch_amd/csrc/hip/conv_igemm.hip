@@ -507,21 +507,26 @@ static int tile_override() {
 
 // Rows [0, split) go to 128 x 128 tiles, rows [split, M) to 64 x 64 tiles; 0 = no split.  Shared by the launcher and
 // by dpa_conv_stats_rows (the stats slab has one row per M-tile of either size).
-static int tail_split_rows(int M, int dC) {
+static int tail_split_rows(int M, int dC, int elem_bytes, int BM = 128, int BN = 128) {
   static const int enabled = [] { const char* e = getenv("DPA_CONV_TAILSPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const int rem_env = [] { const char* e = getenv("DPA_CONV_TAILSPLIT_REM"); return e ? atoi(e) : 0; }();
   if (!enabled) return 0;
-  // The 128 x 128 kernel is resident twice per CU and the dispatcher refills freed slots two at a time, so the
-  // quantum that matters is a ROUND of 2 x 256 tiles (measured: 512 tiles 318 us, 784 tiles 595 us, 1024 tiles 592 us
-  // in fp32, scripts/conv_size_sweep.py).  Split only when the last round would be at most a quarter full: its rows
-  // then become <= 512 quarter-size tiles, i.e. at most two per CU.
-  const int CUS = 512;
-  const long long tm = (M + 127) / 128, tn = (dC + 127) / 128, tiles = tm * tn;
-  const long long full = tiles / CUS;                 // whole rounds
-  const long long rem = tiles - full * CUS;           // tiles of the last, partial round
-  if (full < 1 || rem == 0 || rem * 4 > CUS) return 0;
-  const long long big_rows = (full * CUS) / tn;       // M-tiles kept as big tiles
+  // measured (scripts/bench_conv_layers.py): fp32 gains up to a 320-tile tail (-2 % conv time), the LDS/L2-bound bf16
+  // kernel only up to 128 (small tiles cost it more per FLOP)
+  const int max_rem = rem_env > 0 ? rem_env : (elem_bytes == 4 ? 320 : 128);
+  // The big-tile kernels (128 x 128, 256 x 64) are resident twice per CU and the dispatcher refills freed slots two at a
+  // time, so the quantum that matters is a ROUND of 2 x 256 tiles (measured: 512 tiles 318 us, 784 tiles 595 us, 1024
+  // tiles 592 us in fp32, scripts/conv_size_sweep.py).  The 64 x 64 kernel is resident 5 times per CU (1280 slots) and a
+  // big tile is 4 small ones, so a last round of up to 320 big tiles fits ONE round of small tiles, which takes about
+  // 0.75 of a big round (fp32): split whenever the partial round holds at most `max_rem` tiles.
+  const int ROUND = 512;
+  const long long tm = (M + BM - 1) / BM, tn = (dC + BN - 1) / BN, tiles = tm * tn;
+  const long long full = tiles / ROUND;               // whole rounds
+  const long long rem = tiles - full * ROUND;         // tiles of the last, partial round
+  if (full < 1 || rem == 0 || rem > max_rem) return 0;
+  const long long big_rows = (full * ROUND) / tn;     // M-tiles kept as big tiles
   if (big_rows <= 0 || big_rows >= tm) return 0;
-  return (int)(big_rows * 128);
+  return (int)(big_rows * BM);
 }
 
 template <typename T>
@@ -534,15 +539,24 @@ static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
   const long long big_tiles = (long long)((p.M + 127) / 128) * ((p.dC + 127) / 128);
   if (p.dC <= 32)                     launch_cfg<T, 4, 1, 2, 2>(p, dgrad, s);   // 128 x 32
   else if (p.dC <= 64) {
-    if ((p.M + 255) / 256 >= 256)     launch_cfg<T, 4, 1, 4, 4>(p, dgrad, s);   // 256 x 64
-    else                              launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
+    if ((p.M + 255) / 256 >= 256) {                                             // 256 x 64 (+ 64 x 64 tail)
+      const int split = tail_split_rows(p.M, p.dC, (int)sizeof(T), 256, 64);
+      if (split > 0) {
+        ConvParams a = p; a.M = split;
+        launch_cfg<T, 4, 1, 4, 4>(a, dgrad, s);
+        ConvParams b = p; b.m_off = split; b.stats_row0 = split / 256;
+        launch_cfg<T, 2, 2, 2, 2>(b, dgrad, s);
+      } else {
+        launch_cfg<T, 4, 1, 4, 4>(p, dgrad, s);
+      }
+    } else                            launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);   // 64 x 64
   } else if (tile_override() == 64)   launch_cfg<T, 2, 2, 2, 2>(p, dgrad, s);
   else if (tile_override() == 12864)  launch_cfg<T, 2, 2, 4, 2>(p, dgrad, s);   // 128 x 64
   else if (big_tiles >= big_min()) {
     // 128 x 128 tiles run in rounds of 512 (2 per CU); a nearly empty last round costs a full round.  Give whole
     // rounds to the big tiles and the few remaining rows to a second launch of 64 x 64 tiles (quarter-size work
     // items that spread over the chip): e.g. 1568 tiles = 3.06 rounds -> 3 rounds + a short tail instead of 4.
-    const int split = tail_split_rows(p.M, p.dC);
+    const int split = tail_split_rows(p.M, p.dC, (int)sizeof(T));
     if (split > 0) {
       ConvParams a = p; a.M = split;
       launch_cfg<T, 2, 2, 4, 4>(a, dgrad, s);
@@ -594,14 +608,19 @@ DPA_API int dpa_conv_igemm(ConvParams* p, int dtype, int dgrad, hipStream_t s) {
   return dtype == 1 ? launch_conv<bf16_t>(q, dgrad, s) : launch_conv<float>(q, dgrad, s);
 }
 // rows of the per-block stats slab a launch with these dims will write (tilesM of the chosen config)
-DPA_API int dpa_conv_stats_rows(int M, int dC) {
+DPA_API int dpa_conv_stats_rows(int M, int dC, int dtype) {
+  const int eb = dtype == 1 ? 2 : 4;
   const long long big_tiles = (long long)((M + 127) / 128) * ((dC + 127) / 128);
   if (dC <= 32) return (M + 127) / 128;
-  if (dC <= 64) return ((M + 255) / 256 >= 256) ? (M + 255) / 256 : (M + 63) / 64;
+  if (dC <= 64) {
+    if ((M + 255) / 256 < 256) return (M + 63) / 64;
+    const int split = tail_split_rows(M, dC, eb, 256, 64);
+    return split > 0 ? split / 256 + (M - split + 63) / 64 : (M + 255) / 256;
+  }
   if (tile_override() == 64) return (M + 63) / 64;
   if (tile_override() == 12864) return (M + 127) / 128;
   if (big_tiles >= big_min()) {
-    const int split = tail_split_rows(M, dC);
+    const int split = tail_split_rows(M, dC, eb);
     return split > 0 ? split / 128 + (M - split + 63) / 64 : (M + 127) / 128;
   }
   return (M + 63) / 64;

@@ -224,7 +224,7 @@ class BatchNorm2d:
 
 
 def _stats_slab(ctx, m, c, conv_fused):
-    rows = ops.stats_rows(m, c, ctx.cuda) if conv_fused else ops.bn_slab_rows(m, ctx.cuda)
+    rows = ops.stats_rows(m, c, ctx.cuda, ctx.dtype) if conv_fused else ops.bn_slab_rows(m, ctx.cuda)
     return workspace(ctx.device, rows * 2 * c, "bn_slab")[: rows * 2 * c].view(rows, 2, c)
 
 

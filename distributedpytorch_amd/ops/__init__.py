@@ -2,6 +2,8 @@
 plain-PyTorch reference (ref_ops, also the test oracle).  The first positional argument decides."""
 from __future__ import annotations
 
+import torch
+
 from . import ref_ops
 
 _hip_ops = None
@@ -45,8 +47,8 @@ out_size = ref_ops.out_size
 pool_out_size = ref_ops.pool_out_size
 
 
-def stats_rows(m, cout, cuda):
-    return _hip().stats_rows(m, cout) if cuda else 1
+def stats_rows(m, cout, cuda, dtype=torch.float32):
+    return _hip().stats_rows(m, cout, dtype) if cuda else 1
 
 
 def bn_slab_rows(m, cuda):

@@ -112,5 +112,7 @@ def conv_wgrad(dy, x, dw, ksize, stride, pad, workspace=None, accumulate=False):
     return dw
 
 
-def stats_rows(m, cout):
-    return int(native.hip_lib().dpa_conv_stats_rows(int(m), int(cout)))
+def stats_rows(m, cout, dtype=torch.float32):
+    """Rows of the BN-statistics slab a conv_fprop over m rows x cout columns writes (depends on the tile plan, which
+    depends on the dtype)."""
+    return int(native.hip_lib().dpa_conv_stats_rows(int(m), int(cout), 1 if dtype == torch.bfloat16 else 0))

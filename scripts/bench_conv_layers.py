@@ -40,7 +40,7 @@ for (h, ci, co, k, s, p, cnt) in LAYERS:
     dx = torch.empty_like(x)
     dw = torch.empty(co, k, k, ci, device="cuda")
     ws = torch.empty(H.wgrad_workspace_numel(co, k * k * ci), device="cuda")
-    stats = torch.empty(H.stats_rows(N * ho * ho, co), 2, co, device="cuda")
+    stats = torch.empty(H.stats_rows(N * ho * ho, co, dt), 2, co, device="cuda")
     fl = 2.0 * N * ho * ho * co * k * k * ci
     tf = timeit(lambda: H.conv_fprop(x, w, y, (s, s), (p, p), stats=stats))
     td = timeit(lambda: H.conv_dgrad(dy, wt, dx, (s, s), (p, p)))

@@ -44,7 +44,7 @@ def test_conv_fprop_dgrad_wgrad(shape, dtype):
     w = (torch.randn(K, k, k, C, device="cuda", generator=g) * (k * k * C) ** -0.5).to(dtype)
     Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
     y = torch.full((N, Ho, Wo, K), float("nan"), device="cuda", dtype=dtype)
-    rows = hip_conv.stats_rows(N * Ho * Wo, K)
+    rows = hip_conv.stats_rows(N * Ho * Wo, K, dtype)
     stats = torch.zeros(rows, 2, K, device="cuda")
     hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd), stats=stats)
     xr = x.float().requires_grad_(True)
