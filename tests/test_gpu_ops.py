@@ -165,7 +165,7 @@ def test_avgpool(cfg, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("nc", [(64, 10), (37, 1000)])
+@pytest.mark.parametrize("nc", [(64, 10), (37, 1000), (203, 1000)])     # the last one takes the multi-block path
 def test_ce_loss(nc, mode, dtype):
     from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
     n, c = nc
