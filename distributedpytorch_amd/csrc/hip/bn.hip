@@ -275,13 +275,15 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
 }
 
 static int ew_rows_per_block(long long M, int* nblocks) {
-  long long rpb = (M + 2047) / 2048;
+  static const int target = [] { const char* e = getenv("DPA_BN_EW_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+  long long rpb = (M + target - 1) / target;
   if (rpb < 16) rpb = 16;
   *nblocks = (int)((M + rpb - 1) / rpb);
   return (int)rpb;
 }
 static int rows_per_block(long long M, int* nblocks) {
-  long long rpb = (M + 1023) / 1024;
+  static const int target = [] { const char* e = getenv("DPA_BN_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  long long rpb = (M + target - 1) / target;
   if (rpb < 8) rpb = 8;
   *nblocks = (int)((M + rpb - 1) / rpb);
   return (int)rpb;
