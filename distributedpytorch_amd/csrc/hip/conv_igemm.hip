@@ -338,16 +338,27 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_k
     }
     __builtin_amdgcn_wave_barrier();
     if (p.stats) {
+      if (m0 + BM <= p.M) {                        // interior tile (block-uniform): no per-element row check
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int m = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
-          float v = acc[i][j][e] + bj[j];
-          if (sizeof(T) == 2) v = bf2f(f2bf(v));   // statistics of the values as stored
-          if (m >= p.M) v = 0.f;
-          csum[j] += v; csq[j] += v * v;
-        }
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][e] + bj[j];
+            if (sizeof(T) == 2) v = bf2f(f2bf(v));   // statistics of the values as stored
+            csum[j] += v; csq[j] += v * v;
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
+            float v = acc[i][j][e] + bj[j];
+            if (sizeof(T) == 2) v = bf2f(f2bf(v));
+            if (m >= p.M) v = 0.f;
+            csum[j] += v; csq[j] += v * v;
+          }
+      }
     }
   }
   if (p.stats) {
