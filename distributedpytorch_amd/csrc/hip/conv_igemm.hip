@@ -608,6 +608,9 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
       q.base_x = (q.cls_w0 + p.pw - b) / p.sw;
       q.M = p.sN * q.cls_nh * q.cls_nw;
       q.Kg = q.nR * q.nS * p.sC;          // 0 taps: the kernel only runs its epilogue (zeros + addend)
+      // ... and when the addend IS the destination (in-place accumulation into an existing gradient) a class without
+      // taps leaves its pixels unchanged: nothing to launch (3 of the 4 classes of a 1x1 stride-2 downsample conv)
+      if (q.Kg == 0 && p.addend == p.dst) continue;
       launch_tiles<T>(q, 1, s);
     }
   return 0;

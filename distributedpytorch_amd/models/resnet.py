@@ -26,8 +26,10 @@ class BasicBlock:
             self.down = _cb(store, prefix, "downsample.0", "downsample.1", cin, planes, 1, stride, 0, trainable)
 
     def __call__(self, ctx: Context, x: Act) -> Act:
-        out = self.c1(ctx, x, relu=True)
+        # the downsample branch runs FIRST so that, in the reversed backward order, its dgrad comes after conv1's and
+        # accumulates in place into x.grad: the stride-2 1x1 dgrad then touches only 1/4 of the pixels
         identity = x if self.down is None else self.down(ctx, x, relu=False)
+        out = self.c1(ctx, x, relu=True)
         return self.c2(ctx, out, relu=True, residual=identity)
 
 
@@ -43,9 +45,9 @@ class Bottleneck:
             self.down = _cb(store, prefix, "downsample.0", "downsample.1", cin, planes * 4, 1, stride, 0, trainable)
 
     def __call__(self, ctx: Context, x: Act) -> Act:
+        identity = x if self.down is None else self.down(ctx, x, relu=False)      # first: see BasicBlock
         out = self.c1(ctx, x, relu=True)
         out = self.c2(ctx, out, relu=True)
-        identity = x if self.down is None else self.down(ctx, x, relu=False)
         return self.c3(ctx, out, relu=True, residual=identity)
 
 
