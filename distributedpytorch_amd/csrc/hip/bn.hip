@@ -12,7 +12,7 @@
 // All slabs are reduced in a fixed order: results are bitwise reproducible (no float atomics).
 #include "common.h"
 
-#define ROWS_L2 32   // rows of the second-level slab
+#define ROWS_L2 128  // rows of the second-level slab (= blocks along the row axis of slab_reduce: 32 left most CUs idle)
 
 template <typename T>
 __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, long long M, int C, int cs,
@@ -53,13 +53,13 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// [rows][width] -> [ROWS_L2][width]; out row j sums rows j, j+32, ... (fixed order)
+// [rows][width] -> [ROWS_L2][width]; out row j sums rows j, j+ROWS_L2, ... (fixed order)
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ in, int rows, int width,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, int groups) {
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= width) return;
   float s = 0.f;
-  for (int r = blockIdx.x; r < rows; r += ROWS_L2) s += in[(size_t)r * width + c];
+  for (int r = blockIdx.x; r < rows; r += groups) s += in[(size_t)r * width + c];
   out[(size_t)blockIdx.x * width + c] = s;
 }
 
@@ -292,8 +292,11 @@ static int rows_per_block(long long M, int* nblocks) {
 // Reduce a [rows][2][C] slab down to <= ROWS_L2 rows if it is tall. Returns the slab to finalize from.
 static const float* shrink_slab(const float* slab, int* rows, int C, float* scratch, hipStream_t s) {
   if (*rows <= 64) return slab;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(ROWS_L2, (2 * C + 255) / 256), dim3(256), 0, s, slab, *rows, 2 * C, scratch);
-  *rows = ROWS_L2;
+  // tall slabs (large batches: 25 088 rows at batch 1024) get 128 row groups so that the reduction covers the chip;
+  // small ones stay at 32 (the finalize kernel walks the groups serially)
+  const int groups = *rows >= 2048 ? ROWS_L2 : 32;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(groups, (2 * C + 255) / 256), dim3(256), 0, s, slab, *rows, 2 * C, scratch, groups);
+  *rows = groups;
   return scratch;
 }
 
