@@ -51,6 +51,15 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["DPA_WATCHDOG_S"]), exit=True)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # convenience: `python bench.py --gpus N` without a launcher starts the N ranks itself (as a child process,
+        # before anything touches the GPU) exactly the way the driver does
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29512"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
