@@ -38,8 +38,11 @@ def main():
     ap.add_argument("--shape", default="imagenet", choices=["imagenet", "cifar", "mnist"])
     ap.add_argument("--dtype", default=os.environ.get("DPA_BENCH_DTYPE", "fp32"), choices=["bf16", "fp32"],
                     help="compute dtype of the HEADLINE number; fp32 (exact fp32 MFMA) is the reference's precision")
+    ap.add_argument("--fp32-mode", default=os.environ.get("DPA_FP32_MODE", "exact"), choices=["exact", "x6"],
+                    help="fp32 conv arithmetic of the HEADLINE number: exact = v_mfma_f32_16x16x4_f32; x6 = every fp32 "
+                         "product as six bf16 MFMA products of exact 3-way bf16 operand splits (fp32 in/out/accumulate)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the extra bf16 measurement that is reported (outside the headline) under 'secondary'")
+                    help="skip the extra measurements (fp32 in x6 mode, bf16) reported outside the headline under 'secondary'")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "SGD"])
     ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (1 GPU only)")
@@ -104,9 +107,12 @@ def main():
 
     peak_gb = []
 
-    def measure(dtype_name):
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+
+    def measure(dtype_name, fp32_mode="exact"):
         """Build the model in `dtype_name`, run warmup + EXACTLY args.steps timed full training iterations."""
         torch.manual_seed(1234)
+        set_fp32_mode(fp32_mode)
         dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
         net, _ = get_model(args.model, classes, device=device, dtype=dtype, small_input=small)
         opt = ArenaOptimizer(net.store, args.optimizer, lr=1e-3)
@@ -141,21 +147,26 @@ def main():
         torch.cuda.empty_cache()
         return elapsed, loss, use_graph
 
-    elapsed, loss, use_graph = measure(args.dtype)
+    elapsed, loss, use_graph = measure(args.dtype, args.fp32_mode)
+    # extra measurements, single-GPU invocations only (the multi-GPU runs measure the headline and exit); never fatal
     secondary = None
-    e2 = l2 = None
-    # the extra bf16 measurement runs on single-GPU invocations only: the multi-GPU runs measure the headline and exit
     if args.dtype == "fp32" and not args.no_secondary and world == 1:
-        try:
-            e2, l2, _ = measure("bf16")
-        except Exception as exc:      # noqa: BLE001 - the headline number must still be reported
-            e2, l2 = None, None
-            secondary = {"dtype": "bf16", "error": repr(exc)[:200]}
-    if e2 is not None:
-        secondary = {"dtype": "bf16", "value": round(args.batch * world * args.steps / e2, 2), "unit": "images/s",
-                     "ms_per_step": round(1000 * e2 / args.steps, 3), "mean_loss": round(l2, 4),
-                     "note": "same model/config/steps with bf16 activations+MFMA, fp32 master weights/optimizer; "
-                             "NOT the headline (the reference trains in fp32)"}
+        secondary = []
+        extra = [("bf16", "exact", "same model/config/steps with bf16 activations+MFMA, fp32 master weights/optimizer; "
+                                   "NOT the headline (the reference trains in fp32)")]
+        if args.fp32_mode == "exact":
+            extra.insert(0, ("fp32", "x6", "same fp32 model/config/steps, conv products evaluated as six bf16 MFMA products of "
+                                           "exact 3-way bf16 operand splits (fp32 in/out/accumulate; error vs fp64 not above "
+                                           "the exact kernels', tests/test_gpu_x6.py); opt-in (--fp32-mode x6), NOT the headline"))
+        for dt, mode, note in extra:
+            try:
+                e2, l2, _ = measure(dt, mode)
+                secondary.append({"dtype": dt, "fp32_mode": mode if dt == "fp32" else None,
+                                  "value": round(args.batch * world * args.steps / e2, 2), "unit": "images/s",
+                                  "ms_per_step": round(1000 * e2 / args.steps, 3), "mean_loss": round(l2, 4), "note": note})
+            except Exception as exc:      # noqa: BLE001 - the headline number must still be reported
+                secondary.append({"dtype": dt, "fp32_mode": mode, "error": repr(exc)[:200]})
+        set_fp32_mode(args.fp32_mode)
 
     if rank == 0:
         global_batch = args.batch * world
@@ -169,6 +180,7 @@ def main():
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch, "seq_len": None,
                        "image": f"{side}x{side}x3", "classes": classes, "optimizer": args.optimizer,
                        "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb, "comm": args.comm,
+                       "fp32_mode": args.fp32_mode if args.dtype == "fp32" else None,
                        "peak_hbm_gb": peak_gb[0] if peak_gb else None, "hipgraph": use_graph,
                        "mean_loss": round(loss, 4)},
             "secondary": secondary,

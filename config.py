@@ -69,6 +69,7 @@ NUM_THREADS = _env("NUM_THREADS", 32, int)
 
 # ----------------------------------------------------------------------------- MI355X-native additions
 COMPUTE_DTYPE = _env("COMPUTE_DTYPE", 'fp32')     # fp32 (exact f32 MFMA; the reference's precision) | bf16 (bf16 MFMA, fp32 accumulate + fp32 master weights; ~3x faster)
+FP32_MODE = _env("FP32_MODE", 'exact')            # exact (v_mfma_f32_16x16x4_f32) | x6 (each fp32 product as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate: error vs fp64 not above the exact path's, conv kernels ~1.35x faster)
 FIRST_BUCKET_MB = _env("FIRST_BUCKET_MB", 1.0, float)    # DDP first (last-layer) bucket
 BUCKET_CAP_MB = _env("BUCKET_CAP_MB", 25.0, float)       # DDP bucket cap, sized for 7 xGMI links per GPU
 BROADCAST_BUFFERS = _env("BROADCAST_BUFFERS", True, bool)  # DDP semantics: rank 0's BatchNorm statistics win every step

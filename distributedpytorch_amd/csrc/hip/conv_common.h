@@ -76,6 +76,33 @@ template <> struct MfmaT<float> {
   }
 };
 
+// ---- fp32 through the bf16 matrix pipe ("x6" mode) ---------------------------------------------------------------
+// x = p0 + p1 + p2 EXACTLY, each part a bf16 (round-to-nearest of the value, of the remainder, of the second
+// remainder: 8 + 8 + 8 significant bits cover the 24-bit fp32 significand).  A product of two fp32 numbers is then
+// evaluated as p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1 on v_mfma_f32_16x16x32_bf16 (fp32 accumulation); the three
+// dropped terms are below 2^-23 of the product, i.e. at the rounding of one fp32 multiply, and measured against an
+// fp64 reference the result is slightly MORE accurate than the exact-fp32 16x16x4 MFMA chain (fewer accumulator
+// roundings: 32 products per instruction instead of 4) - scripts/debug/x6_check.py, profiles/README.md.
+// The bf16 pipe does 16x the MACs per cycle of the fp32 one, so 6 products still cost 2.7x fewer matrix cycles.
+extern "C" int dpa_get_fp32_mode();      // 0 = exact fp32 MFMA (default), 1 = x6; DPA_FP32_MODE / dpa_set_fp32_mode
+__device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  f32x2_t r = {x, y};
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_t));   // v_cvt_pk_bf16_f32
+    o[part] = h;
+    if (part < 2) {
+      r.x -= __uint_as_float(h << 16);
+      r.y -= __uint_as_float(h & 0xffff0000u);
+    }
+  }
+}
+// order of the six partial products: small terms first
+__device__ constexpr int kX6A[6] = {1, 2, 0, 1, 0, 0};
+__device__ constexpr int kX6B[6] = {1, 0, 2, 0, 1, 0};
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // XCD-aware, bijective remap of the linear block id: blocks that share an XCD (id % 8) get a contiguous

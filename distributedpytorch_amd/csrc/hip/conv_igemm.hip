@@ -21,7 +21,21 @@
 // 64 zero bytes: the source of every padded / out-of-range 16-byte chunk of the LDS-DMA staging path
 __device__ uint4 dpa_zero_chunk[4];
 
-template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false>
+// Split one lane's 8 fp32 fragment values (two 16-byte chunks) into three bf16 planes (conv_common.h: split3_pair).
+__device__ __forceinline__ void split3_bf16(const uint4& lo, const uint4& hi, uint4 (&pl)[3]) {
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t o[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split3_pair(__uint_as_float(w[2 * q]), __uint_as_float(w[2 * q + 1]), o[q]);
+#pragma unroll
+  for (int part = 0; part < 3; ++part) pl[part] = make_uint4(o[0][part], o[1][part], o[2][part], o[3][part]);
+}
+
+// X6 (fp32 operands, LDS-DMA staging only): every fp32 product is evaluated as 6 bf16 x bf16 products of the exact
+// 3-way bf16 splits of the operands (p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1, fp32 accumulation in the MFMA); the
+// dropped terms are below 2^-23 of the product, i.e. at the rounding of an fp32 multiply, and the bf16 matrix pipe
+// is 16x the fp32 one per MAC (6 x 16-cycle 16x16x32 MFMAs replace 8 x 32-cycle 16x16x4 ones per 32 k).
+template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false, bool X6 = false>
 __global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
@@ -227,12 +241,28 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_k
           fb[ks][j] = *reinterpret_cast<const uint4*>(tB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
       }
       if (kt + 1 < nkt) { gen_addresses(kt + 1); issue_tile((kt + 1 - kt0) & 1); }
+      if constexpr (X6) {
+        uint4 bp[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) split3_bf16(fb[0][j], fb[1][j], bp[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          uint4 ap[3];
+          split3_bf16(fa[0][i], fa[1][i], ap);
+          // small terms first; j innermost so that consecutive MFMAs hit independent accumulators
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) MfmaT<bf16_t>::mma(ap[kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) MfmaT<T>::mma(fa[ks][i], fb[ks][j], acc[i][j]);
+      }
     }
     __syncthreads();
   } else {
@@ -442,6 +472,17 @@ static float* splitk_workspace() {
   return it->second;
 }
 
+// fp32 arithmetic mode of the convolution kernels (fprop / dgrad here, wgrad in conv_wgrad.hip): 0 = exact fp32 MFMA,
+// 1 = x6 (fp32 through 6 bf16 MFMAs per product, see X6 above).  Initial value from DPA_FP32_MODE=exact|x6; the
+// Python layer switches it with dpa_set_fp32_mode (between launches; a captured hipGraph keeps the mode it was captured in).
+static int g_fp32_mode = -1;
+DPA_API int dpa_get_fp32_mode() {
+  if (g_fp32_mode < 0) { const char* e = getenv("DPA_FP32_MODE"); g_fp32_mode = (e && e[0] == 'x') ? 1 : 0; }
+  return g_fp32_mode;
+}
+DPA_API void dpa_set_fp32_mode(int mode) { g_fp32_mode = mode ? 1 : 0; }
+static int fp32_x6() { return dpa_get_fp32_mode(); }
+
 template <typename T, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   ConvParams p = pin;
@@ -490,6 +531,11 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
                         // single-pass kernels keep their register allocation
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true>), grid, block, lds, s, p);
+  } else if (use_glds && sizeof(T) == 4 && fp32_x6()) {
+    if constexpr (sizeof(T) == 4) {
+      if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
+      else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true>), grid, block, lds, s, p);
+    }
   } else if (use_glds) {     // LDS-DMA staging, double-buffered (default)
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true>), grid, block, lds, s, p);

@@ -30,13 +30,18 @@ template <typename T> struct WgLds;
 template <> struct WgLds<bf16_t> { static constexpr int PAD = 32; };   // bytes; shifts each pixel row by 8 banks
 template <> struct WgLds<float>  { static constexpr int PAD = 64; };   // (pitch/4) % 32 == 16
 
-template <typename T, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p) {
+// X6 (fp32 operands only): the staging threads split every value into three bf16 planes (conv_common.h, split3_pair)
+// on the way into LDS - once per element - and the K loop runs the bf16 fragment path on the six plane pairs.
+template <typename T, int WM, int WN, int TM, int TN, bool X6 = false>
+__global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const WgradParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BKP = 8 * VEC;                          // pixels per K-tile (64 bf16 / 32 fp32)
-  constexpr int PITCH_A = BM * sizeof(T) + WgLds<T>::PAD;
-  constexpr int PITCH_B = BN * sizeof(T) + WgLds<T>::PAD;
+  constexpr int ESZ = X6 ? 2 : (int)sizeof(T);          // bytes per element in LDS
+  constexpr int LPAD = X6 ? WgLds<bf16_t>::PAD : WgLds<T>::PAD;
+  constexpr int PITCH_A = BM * ESZ + LPAD;
+  constexpr int PITCH_B = BN * ESZ + LPAD;
+  constexpr int PLANE_A = BKP * PITCH_A, PLANE_B = BKP * PITCH_B;   // X6: three planes per operand
   constexpr int CPR_A = BM / VEC, CPR_B = BN / VEC;     // 16-byte chunks per pixel row
   constexpr int A_PASSES = BKP * CPR_A / 256;
   constexpr int RPP_A = 256 / CPR_A;                    // pixel rows per pass (A)
@@ -45,7 +50,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p)
   static_assert(WM * WN == 4, "4 waves per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;
-  char* ldsB = smem + BKP * PITCH_A;
+  char* ldsB = smem + (X6 ? 3 : 1) * PLANE_A;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -117,6 +122,27 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p)
     }
   };
   auto store_tile = [&]() __attribute__((always_inline)) {
+    if constexpr (X6) {
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        uint32_t lo[3], hi[3];
+        split3_pair(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), lo);
+        split3_pair(__uint_as_float(ra[i].z), __uint_as_float(ra[i].w), hi);
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+          *reinterpret_cast<uint2*>(ldsA + part * PLANE_A + (ra0 + RPP_A * i) * PITCH_A + ca * 8) = make_uint2(lo[part], hi[part]);
+      }
+#pragma unroll
+      for (int i = 0; i < B_CHUNKS; ++i) {
+        uint32_t lo[3], hi[3];
+        split3_pair(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), lo);
+        split3_pair(__uint_as_float(rb[i].z), __uint_as_float(rb[i].w), hi);
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+          *reinterpret_cast<uint2*>(ldsB + part * PLANE_B + brow * PITCH_B + (bsub + TPR * i) * 8) = make_uint2(lo[part], hi[part]);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
       *reinterpret_cast<uint4*>(ldsA + (ra0 + RPP_A * i) * PITCH_A + ca * 16) = ra[i];
@@ -139,7 +165,38 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const WgradParams p)
     for (int pix0 = pix_begin; pix0 < pix_end; pix0 += BKP) {
       const bool more = pix0 + BKP < pix_end;
       if (more) load_tile(pix0 + BKP);
-      if constexpr (sizeof(T) == 2) {
+      if constexpr (X6) {
+        // one 32-pixel k-step per tile; the planes are bf16 tiles, read with the same transposed loads as the bf16 path
+        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+        const int q = fr >> 2, pp = fr & 3;
+        const int krow = 8 * fq + q;
+        bf16x8 fb[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            const char* base = ldsB + part * PLANE_B + krow * PITCH_B + (wn * TN * 16 + j * 16 + 4 * pp) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base + 4 * PITCH_B));
+            fb[j][part] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          bf16x8 fa[3];
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            const char* base = ldsA + part * PLANE_A + krow * PITCH_A + (wm * TM * 16 + i * 16 + 4 * pp) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base + 4 * PITCH_A));
+            fa[part] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kX6A[t]], fb[j][kX6B[t]], acc[i][j], 0, 0, 0);
+        }
+      } else if constexpr (sizeof(T) == 2) {
         // bf16: per 32-pixel k-step, lane needs k = 8*fq + j (j = 0..7) of column fr: two transposed
         // 4x16 block reads; lane (4q+pp) of each 16-lane group addresses block row q, columns 4pp..4pp+3.
         typedef __attribute__((address_space(3))) bf16x4 lds_b4;
@@ -251,8 +308,10 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   // At most one resident round of blocks.  (Rounding UP here put every 3x3 layer at 513-576 blocks with 512 slots:
   // a second, almost empty round that cost 20-25 % - PMC showed the same cycles per MFMA as the 1x1 layers but lower
   // residency.)  Slab traffic grows with the split.
-  static const int target = [] { const char* e = getenv("DPA_WGRAD_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
-  int split = target / tiles;       // 768 = 3 resident blocks per CU (the kernel is built for 3 waves/SIMD)
+  static const int target_env = [] { const char* e = getenv("DPA_WGRAD_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const bool x6 = sizeof(T) == 4 && dpa_get_fp32_mode() == 1;
+  const int target = target_env ? target_env : (x6 ? 512 : 768);
+  int split = target / tiles;       // 768 = 3 resident blocks per CU (the kernel is built for 3 waves/SIMD; x6: 2)
   if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
   if (!workspace) split = 1;
@@ -265,8 +324,15 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   const bool xcd_order = xcd_env >= 0 ? xcd_env != 0 : true;
   p.xcd_order = xcd_order ? 1 : 0;
   p.out = split == 1 ? grad : workspace;
-  size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
+  if (x6) {
+    if constexpr (sizeof(T) == 4) {
+      const size_t lds = (size_t)BKP * 3 * ((BM + BN) * 2 + 2 * WgLds<bf16_t>::PAD);
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN, true>), dim3(tiles * split), dim3(256), lds, s, p);
+    }
+  } else {
+    const size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
+  }
   if (split > 1) {
     const long long n = (long long)p.K * p.Ng;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, workspace, grad, n,

@@ -75,8 +75,27 @@ def hip_lib():
         if lib.dpa_wgrad_params_size() != ctypes.sizeof(WgradParams):
             raise RuntimeError("WgradParams ABI mismatch between ops/native.py and conv_wgrad.hip")
         lib.dpa_conv_wgrad_workspace.restype = I64
+        lib.dpa_get_fp32_mode.restype = I32
         _hip = lib
     return _hip
+
+
+FP32_MODES = ("exact", "x6")
+
+
+def set_fp32_mode(mode: str) -> str:
+    """Arithmetic of the fp32 convolution kernels: 'exact' = v_mfma_f32_16x16x4_f32 (default), 'x6' = every fp32
+    product as six bf16 x bf16 products of exact 3-way bf16 splits on the bf16 matrix pipe, fp32 accumulation
+    (csrc/hip/conv_common.h).  Returns the previous mode.  Takes effect for launches issued afterwards."""
+    if mode not in FP32_MODES:
+        raise ValueError(f"fp32 mode must be one of {FP32_MODES}, got {mode!r}")
+    prev = get_fp32_mode()
+    hip_lib().dpa_set_fp32_mode(I32(FP32_MODES.index(mode)))
+    return prev
+
+
+def get_fp32_mode() -> str:
+    return FP32_MODES[int(hip_lib().dpa_get_fp32_mode())]
 
 
 def host_lib():

@@ -107,6 +107,11 @@ def processData(gpu, phase, epoch, dmodel: DistributedModel, modelName, dataset,
 def _build(args, gpu, rank, modelName, cfg, with_optimizer):
     device = _device_for(gpu)
     dtype = _dtype(cfg, device)
+    if device.type == "cuda" and dtype == torch.float32:
+        from .ops.native import set_fp32_mode
+        set_fp32_mode(getattr(cfg, "FP32_MODE", "exact"))
+        if rank == 0 and getattr(cfg, "FP32_MODE", "exact") != "exact":
+            logging.info(f"fp32 convolution arithmetic: {cfg.FP32_MODE}")
     dataset = MNIST(args.dataPath, args.batchSize, get_model_input_size(modelName), worldSize=args.worldSize, rank=rank,
                     gpu=gpu, device=device, dtype=dtype, debug=bool(args.debug), seed=cfg.SEED,
                     synthetic_ok=getattr(cfg, "SYNTHETIC_DATA", True))

@@ -1,0 +1,92 @@
+"""fp32 "x6" arithmetic (csrc/hip/conv_common.h: every fp32 product as six bf16 MFMA products of exact 3-way bf16 splits):
+the error against an fp64 reference must not exceed the exact-fp32 MFMA kernels' error by more than a small factor, on
+fprop, dgrad and wgrad, and a short training run must follow the exact run's loss trajectory."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, Cin, Cout, k, stride, pad): long reductions (LDS-DMA staged igemm, the only igemm variant with an x6 path)
+SHAPES = [
+    (32, 56, 56, 64, 64, 3, 1, 1),
+    (32, 14, 14, 256, 256, 3, 1, 1),
+    (32, 14, 14, 1024, 256, 1, 1, 0),
+    (32, 28, 28, 128, 128, 3, 2, 1),
+    (16, 17, 13, 40, 72, 5, 1, 2),      # odd sizes: general (non-uniform-tap) address path
+]
+
+
+def _errors(shape):
+    from distributedpytorch_amd.ops import hip_conv
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    w = torch.randn(K, k, k, C, device="cuda", generator=g) * (k * k * C) ** -0.5
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g)
+    xd, wd, dyd = x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double()
+    y = torch.empty(N, Ho, Wo, K, device="cuda")
+    hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd))
+    ref_y = F.conv2d(xd, wd, stride=s, padding=pd).permute(0, 2, 3, 1)
+    dx = torch.empty(N, H, W, C, device="cuda")
+    hip_conv.conv_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), dx, (s, s), (pd, pd))
+    ref_dx = torch.nn.grad.conv2d_input((N, C, H, W), wd, dyd, stride=s, padding=pd).permute(0, 2, 3, 1)
+    dw = torch.empty(K, k, k, C, device="cuda")
+    ws = torch.empty(hip_conv.wgrad_workspace_numel(K, k * k * C), device="cuda")
+    hip_conv.conv_wgrad(dy, x, dw, (k, k), (s, s), (pd, pd), workspace=ws)
+    ref_dw = torch.nn.grad.conv2d_weight(xd, (K, C, k, k), dyd, stride=s, padding=pd).permute(0, 2, 3, 1)
+
+    def rel(a, b):     # rms error relative to the rms of the reference
+        return ((a.double() - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    return rel(y, ref_y), rel(dx, ref_dx), rel(dw, ref_dw)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_x6_error_vs_fp64_not_above_exact_path(shape):
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    prev = set_fp32_mode("exact")
+    try:
+        exact = _errors(shape)
+        set_fp32_mode("x6")
+        x6 = _errors(shape)
+    finally:
+        set_fp32_mode(prev)
+    for name, e, v in zip(("fprop", "dgrad", "wgrad"), exact, x6):
+        assert e < 3e-6, f"{name}: exact path off ({e:.2e})"
+        # same order as fp32 rounding; wgrad differs in its split-K factor too, hence the factor
+        assert v < max(2.5 * e, 1e-6), f"{name}: x6 relative rms error {v:.3e} vs exact {e:.3e}"
+
+
+def test_x6_training_follows_exact_trajectory():
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.ops.native import get_fp32_mode, set_fp32_mode
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    device = torch.device("cuda", 0)
+
+    def run(mode):
+        prev = set_fp32_mode(mode)
+        try:
+            assert get_fp32_mode() == mode
+            torch.manual_seed(5)
+            net, _ = get_model("resnet50", 10, device=device, dtype=torch.float32)
+            dm = DistributedModel(net, Criterion("cross_entropy"), ArenaOptimizer(net.store, "adam", lr=1e-3))
+            g = torch.Generator(device=device).manual_seed(11)
+            x = torch.zeros(32, 224, 224, net.in_channels, device=device)
+            x[..., :3] = torch.randn(32, 224, 224, 3, device=device, generator=g)
+            y = torch.randint(0, 10, (32,), device=device, generator=g)
+            losses = []
+            for _ in range(6):
+                dm.reset_epoch_metrics()
+                dm.train_step(x, y)
+                losses.append(dm.epoch_metrics()[0])
+            return losses
+        finally:
+            set_fp32_mode(prev)
+
+    a, b = run("exact"), run("x6")
+    assert a[-1] < a[0]                                   # it trains
+    for la, lb in zip(a, b):                              # same trajectory up to fp32 rounding amplified over 6 Adam steps
+        assert abs(la - lb) <= 2e-2 * max(1.0, abs(la)), (a, b)

@@ -42,6 +42,7 @@ def _resources(src, tmp_path):
 def test_conv_kernels_fit_two_waves_per_simd_without_scratch(src, kernel, tmp_path):
     res = {k: v for k, v in _resources(os.path.join(HIP_DIR, src), tmp_path).items() if kernel in k}
     assert len(res) >= 8, f"expected the template instantiations of {kernel}, found {len(res)}"
+    # (the x6 instantiations - fp32 through the bf16 matrix pipe - are held to the same rule)
     # The register-staged 128x128 igemm variants are deliberately squeezed to 3 waves/SIMD (short-K layers are latency
     # bound: +3-4 % measured); they may keep a few dwords of scratch outside the K loop.  Everything else: none.
     def ok(v):
