@@ -36,7 +36,7 @@ __device__ __forceinline__ void split3_bf16(const uint4& lo, const uint4& hi, ui
 // dropped terms are below 2^-23 of the product, i.e. at the rounding of an fp32 multiply, and the bf16 matrix pipe
 // is 16x the fp32 one per MAC (6 x 16-cycle 16x16x32 MFMAs replace 8 x 32-cycle 16x16x4 ones per 32 k).
 template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false, bool X6 = false>
-__global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
   constexpr int BKE = 8 * VEC;               // reduction elements per K-tile (128-byte rows)
@@ -200,7 +200,37 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_k
   const int kt0 = SPLIT ? split * p.kt_per_split : 0;
   const int nkt = SPLIT ? min(nkt_all, kt0 + p.kt_per_split) : nkt_all;     // this block reduces K-tiles [kt0, nkt)
   const int fr = lane & 15, fq = lane >> 4;
+  // x6: the 8 fp32 values a lane holds per fragment (both k-halves of the tile) become three bf16x8 planes = the
+  // operands of 16x16x32 bf16 MFMAs; small terms first, j innermost so consecutive MFMAs hit independent accumulators
+  auto mma_x6 = [&](const uint4 (&fa)[2][TM], const uint4 (&fb)[2][TN]) __attribute__((always_inline)) {
+    uint4 bp[TN][3];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) split3_bf16(fb[0][j], fb[1][j], bp[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      uint4 ap[3];
+      split3_bf16(fa[0][i], fa[1][i], ap);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MfmaT<bf16_t>::mma(ap[kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+    }
+  };
   auto compute_tile = [&](const char* tA, const char* tB) __attribute__((always_inline)) {
+    if constexpr (X6) {
+      uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wm * TM * 16 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[ks][j] = *reinterpret_cast<const uint4*>(tB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
+      }
+      mma_x6(fa, fb);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 fa[TM], fb[TN];
@@ -242,19 +272,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4) ? 2 : 3)) conv_igemm_k
       }
       if (kt + 1 < nkt) { gen_addresses(kt + 1); issue_tile((kt + 1 - kt0) & 1); }
       if constexpr (X6) {
-        uint4 bp[TN][3];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) split3_bf16(fb[0][j], fb[1][j], bp[j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          uint4 ap[3];
-          split3_bf16(fa[0][i], fa[1][i], ap);
-          // small terms first; j innermost so that consecutive MFMAs hit independent accumulators
-#pragma unroll
-          for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) MfmaT<bf16_t>::mma(ap[kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
-        }
+        mma_x6(fa, fb);
       } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -482,6 +500,10 @@ DPA_API int dpa_get_fp32_mode() {
 }
 DPA_API void dpa_set_fp32_mode(int mode) { g_fp32_mode = mode ? 1 : 0; }
 static int fp32_x6() { return dpa_get_fp32_mode(); }
+static int x6_reg() {       // x6 also for the register-staged (short reduction) variant; DPA_X6_REG=0: A/B switch
+  static const int v = [] { const char* e = getenv("DPA_X6_REG"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
 
 template <typename T, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
@@ -531,10 +553,15 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
                         // single-pass kernels keep their register allocation
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true>), grid, block, lds, s, p);
-  } else if (use_glds && sizeof(T) == 4 && fp32_x6()) {
+  } else if (sizeof(T) == 4 && fp32_x6() && (use_glds || (x6_reg() && WM != 4))) {   // (256 x 64 register-staged x6 would spill)
     if constexpr (sizeof(T) == 4) {
-      if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
-      else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true>), grid, block, lds, s, p);
+      if (use_glds || WM == 4) {
+        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
+        else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true>), grid, block, lds, s, p);
+      } else {
+        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, true>), grid, block, lds, s, p);
+        else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false, false, true>), grid, block, lds, s, p);
+      }
     }
   } else if (use_glds) {     // LDS-DMA staging, double-buffered (default)
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
