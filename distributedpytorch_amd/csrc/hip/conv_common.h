@@ -82,7 +82,7 @@ template <> struct MfmaT<float> {
 // evaluated as p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1 on v_mfma_f32_16x16x32_bf16 (fp32 accumulation); the three
 // dropped terms are below 2^-23 of the product, i.e. at the rounding of one fp32 multiply, and measured against an
 // fp64 reference the result is slightly MORE accurate than the exact-fp32 16x16x4 MFMA chain (fewer accumulator
-// roundings: 32 products per instruction instead of 4) - scripts/debug/x6_check.py, profiles/README.md.
+// roundings: 32 products per instruction instead of 4) - scripts/x6_accuracy.py, profiles/README.md.
 // The bf16 pipe does 16x the MACs per cycle of the fp32 one, so 6 products still cost 2.7x fewer matrix cycles.
 extern "C" int dpa_get_fp32_mode();      // 0 = exact fp32 MFMA (default), 1 = x6; DPA_FP32_MODE / dpa_set_fp32_mode
 __device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) {

@@ -4,7 +4,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributedpytorch_amd.ops import hip_conv
 
 SHAPES = [(64, 56, 56, 64, 64, 3, 1, 1), (64, 14, 14, 256, 256, 3, 1, 1), (64, 14, 14, 1024, 256, 1, 1, 0),
@@ -32,6 +32,6 @@ for (N, H, W, C, K, k, s, pd) in SHAPES:
     refdw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (K, C, k, k), dy.permute(0, 3, 1, 2).double(),
                                         stride=s, padding=pd).permute(0, 2, 3, 1)
     e3 = dw.double() - refdw
-    print(f"   wgrad max|err| {e3.abs().max().item():.3e} rms {e3.pow(2).mean().sqrt().item():.3e} (ref rms {refdw.pow(2).mean().sqrt().item():.3f})")
     print(f"{H}x{W} {C}->{K} k{k} s{s}: fprop max|err| {err.abs().max().item():.3e} rms {err.pow(2).mean().sqrt().item():.3e} "
           f"(ref rms {ref.pow(2).mean().sqrt().item():.3f}) | dgrad max {e2.abs().max().item():.3e} rms {e2.pow(2).mean().sqrt().item():.3e}")
+    print(f"   wgrad max|err| {e3.abs().max().item():.3e} rms {e3.pow(2).mean().sqrt().item():.3e} (ref rms {refdw.pow(2).mean().sqrt().item():.3f})")
