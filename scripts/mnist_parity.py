@@ -140,11 +140,19 @@ def main():
     res["engine_fp32"], sd0 = run_engine(path, torch.float32, a.epochs, a.batch, a.seed)
     print("torch eager fp32 (reference restatement)", flush=True)
     res["torch_fp32"] = run_torch(path, a.epochs, a.batch, a.seed, sd0)
+    print("engine fp32, x6 mode (fp32 products on the bf16 matrix pipe)", flush=True)
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    prev = set_fp32_mode("x6")
+    try:
+        res["engine_fp32_x6"], _ = run_engine(path, torch.float32, a.epochs, a.batch, a.seed, init_sd=sd0)
+    finally:
+        set_fp32_mode(prev)
     print("engine bf16", flush=True)
     res["engine_bf16"], _ = run_engine(path, torch.bfloat16, a.epochs, a.batch, a.seed, init_sd=sd0)
-    summary = {k: round(res[k]["test_acc"], 2) for k in ("torch_fp32", "engine_fp32", "engine_bf16")}
+    runs = ("torch_fp32", "engine_fp32", "engine_fp32_x6", "engine_bf16")
+    summary = {k: round(res[k]["test_acc"], 2) for k in runs}
     res["summary_test_acc_percent"] = summary
-    res["summary_seconds"] = {k: round(res[k]["seconds"], 1) for k in ("torch_fp32", "engine_fp32", "engine_bf16")}
+    res["summary_seconds"] = {k: round(res[k]["seconds"], 1) for k in runs}
     print(json.dumps({"test_acc_percent": summary, "seconds": res["summary_seconds"]}), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
