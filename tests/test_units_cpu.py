@@ -343,3 +343,24 @@ def test_native_reducer_core_protocol():
     lib.dpa_reducer_destroy(core)
     bad = (ctypes.c_int * 1)(7)
     assert not lib.dpa_reducer_create(None, None, 1, bad, 3, lo, hi)   # bucket index out of range
+
+
+def test_fp32_mode_switch_roundtrip():
+    """ops.native.set_fp32_mode / get_fp32_mode (host-side state of the kernel library; no GPU call involved)."""
+    from distributedpytorch_amd.ops import native
+    if not native.have_hip_lib():
+        pytest.skip("kernel library not built")
+    try:
+        native.hip_lib()
+    except OSError:
+        pytest.skip("HIP runtime not loadable on this host")
+    prev = native.get_fp32_mode()
+    try:
+        assert native.set_fp32_mode("x6") == prev
+        assert native.get_fp32_mode() == "x6"
+        assert native.set_fp32_mode("exact") == "x6"
+        assert native.get_fp32_mode() == "exact"
+        with pytest.raises(ValueError):
+            native.set_fp32_mode("tf32")
+    finally:
+        native.set_fp32_mode(prev)
