@@ -558,7 +558,7 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
       if (use_glds || WM == 4) {
         if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true>), grid, block, lds, s, p);
-      } else {
+      } else if constexpr (WM != 4) {     // (not even instantiated for the 256 x 64 tile)
         if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, true>), grid, block, lds, s, p);
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false, false, true>), grid, block, lds, s, p);
       }
