@@ -58,6 +58,12 @@ for name in a.models.split(","):
     rec = {"model": name, "batch": a.batch}
     rec["engine_fp32"] = round(engine(name, torch.float32, False), 1)
     rec["engine_fp32_graph"] = round(engine(name, torch.float32, True), 1)
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    prev = set_fp32_mode("x6")          # fp32 products on the bf16 matrix pipe (opt-in mode)
+    try:
+        rec["engine_fp32_x6_graph"] = round(engine(name, torch.float32, True), 1)
+    finally:
+        set_fp32_mode(prev)
     rec["engine_bf16_graph"] = round(engine(name, torch.bfloat16, True), 1)
     if not a.no_torch:
         rec["torch_eager_fp32"] = round(torch_eager(name), 1)
