@@ -93,3 +93,31 @@ def test_x6_training_follows_exact_trajectory():
     # 1e-3..1e-2 in their gradients (scripts/debug/x6_grad_diff.py).  Identical first step, then a widening band.
     for la, lb, tol in zip(a, b, (1e-4, 3e-2, 1e-1)):
         assert abs(la - lb) <= tol * max(1.0, abs(la)), (a, b)
+
+
+def test_x6_backward_error_with_wide_dynamic_range():
+    """Error relative to sum |a_k||b_k| (the backward-error scale of a dot product) with operands spanning 12 orders of
+    magnitude and full 24-bit significands: the x6 products drop terms below 2^-23 of EACH product, so the bound must hold
+    per output element, not just on average."""
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    N, H, W, C, K, k = 8, 14, 14, 256, 128, 3
+    g = torch.Generator(device="cuda").manual_seed(123)
+    mag = torch.exp2(torch.randint(-20, 20, (N, H, W, C), device="cuda", generator=g).float())
+    x = torch.randn(N, H, W, C, device="cuda", generator=g) * mag
+    w = torch.randn(K, k, k, C, device="cuda", generator=g) * torch.exp2(torch.randint(-10, 10, (K, k, k, C), device="cuda", generator=g).float())
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    scale = F.conv2d(x.permute(0, 3, 1, 2).double().abs(), w.permute(0, 3, 1, 2).double().abs(), padding=1).permute(0, 2, 3, 1)
+    errs = {}
+    prev = set_fp32_mode("exact")
+    try:
+        for mode in ("exact", "x6"):
+            set_fp32_mode(mode)
+            y = torch.empty(N, H, W, K, device="cuda")
+            hip_conv.conv_fprop(x, w, y, (1, 1), (1, 1))
+            assert torch.isfinite(y).all()
+            errs[mode] = ((y.double() - ref).abs() / scale).max().item()
+    finally:
+        set_fp32_mode(prev)
+    assert errs["exact"] < 1e-5, errs
+    assert errs["x6"] < max(2.0 * errs["exact"], 3e-7), errs
