@@ -5,7 +5,7 @@ from distributedpytorch_amd.ops import hip_conv as H
 h, ci, co, k, s, p = [int(v) for v in sys.argv[1:7]]
 mode = sys.argv[7] if len(sys.argv) > 7 else "fprop"
 dt = torch.bfloat16 if (len(sys.argv) <= 8 or sys.argv[8] == "bf16") else torch.float32
-N = 256
+N = int(os.environ.get("DPA_ONE_CONV_BATCH", "256"))
 ho = H.out_size(h, k, s, p)
 x = torch.randn(N, h, h, ci, device="cuda").to(dt)
 w = (torch.randn(co, k, k, ci, device="cuda") * 0.05).to(dt)
