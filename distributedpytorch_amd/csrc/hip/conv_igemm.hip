@@ -551,8 +551,13 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   dim3 grid(ntiles * p.splitK), block(256);
   if (p.splitK > 1) {   // split-K (always a long reduction, hence LDS-DMA staging); a separate instantiation so the
                         // single-pass kernels keep their register allocation
-    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, true>), grid, block, lds, s, p);
-    else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true>), grid, block, lds, s, p);
+    if (sizeof(T) == 4 && fp32_x6()) {
+      if constexpr (sizeof(T) == 4) {
+        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, true, true>), grid, block, lds, s, p);
+        else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true, true>), grid, block, lds, s, p);
+      }
+    } else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, true>), grid, block, lds, s, p);
+    else              hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true>), grid, block, lds, s, p);
   } else if (sizeof(T) == 4 && fp32_x6() && (use_glds || (x6_reg() && WM != 4))) {   // (256 x 64 register-staged x6 would spill)
     if constexpr (sizeof(T) == 4) {
       if (use_glds || WM == 4) {
