@@ -35,7 +35,7 @@ __device__ __forceinline__ void split3_bf16(const uint4& lo, const uint4& hi, ui
 // 3-way bf16 splits of the operands (p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1, fp32 accumulation in the MFMA); the
 // dropped terms are below 2^-23 of the product, i.e. at the rounding of an fp32 multiply, and the bf16 matrix pipe
 // is 16x the fp32 one per MAC (6 x 16-cycle 16x16x32 MFMAs replace 8 x 32-cycle 16x16x4 ones per 32 k).
-template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false, bool X6 = false>
+template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false, bool X6 = false, bool UNI = false>
 __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
   // version spent 4.9 VALU instructions per MFMA here, profiles/README.md).
   const int ntaps = p.nR * p.nS;
   // (a dgrad parity class without taps has Kg == 0: it must take the general path, whose loads are all predicated off)
-  const bool uni = (p.sC % BKE == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni;
+  // UNI: the host has checked the condition - the general path is not even compiled into the K loop
+  const bool uni = UNI || ((p.sC % BKE == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni);
   long long a_rowoff[A_PASSES];
   uint32_t a_mask[A_PASSES];
   if (uni) {
@@ -500,6 +501,10 @@ DPA_API int dpa_get_fp32_mode() {
 }
 DPA_API void dpa_set_fp32_mode(int mode) { g_fp32_mode = mode ? 1 : 0; }
 static int fp32_x6() { return dpa_get_fp32_mode(); }
+static int uni_ct() {       // DPA_CONV_UNICT=0: always launch the instantiations with both address paths (A/B switch)
+  static const int v = [] { const char* e = getenv("DPA_CONV_UNICT"); return e ? atoi(e) : 1; }();
+  return v;
+}
 static int x6_reg() {       // x6 also for the register-staged (short reduction) variant; DPA_X6_REG=0: A/B switch
   static const int v = [] { const char* e = getenv("DPA_X6_REG"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;
@@ -549,6 +554,10 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   }
   if (p.splitK > 1 && lds < (size_t)(BM + BN) * 128 * 2) lds = (size_t)(BM + BN) * 128 * 2;   // split kernels use LDS-DMA staging
   dim3 grid(ntiles * p.splitK), block(256);
+  // The kernel's uniform-tap condition, evaluated here: those launches take instantiations whose K loop contains only
+  // that address path (no loop-invariant branch, half the code in the loop: +2 % on the ResNet-50 step, measured A/B
+  // on one box with DPA_CONV_UNICT=0|1).
+  const bool host_uni = uni_ct() && (p.sC % BKE == 0) && p.nR * p.nS >= 1 && p.nR * p.nS <= 32 && !p.no_uni;
   if (p.splitK > 1) {   // split-K (always a long reduction, hence LDS-DMA staging); a separate instantiation so the
                         // single-pass kernels keep their register allocation
     if (sizeof(T) == 4 && fp32_x6()) {
@@ -560,7 +569,10 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
     else              hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, true>), grid, block, lds, s, p);
   } else if (sizeof(T) == 4 && fp32_x6() && (use_glds || (x6_reg() && WM != 4))) {   // (256 x 64 register-staged x6 would spill)
     if constexpr (sizeof(T) == 4) {
-      if (use_glds || WM == 4) {
+      if ((use_glds || WM == 4) && host_uni) {
+        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true, true>), grid, block, lds, s, p);
+        else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true, true>), grid, block, lds, s, p);
+      } else if (use_glds || WM == 4) {
         if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true>), grid, block, lds, s, p);
       } else if constexpr (WM != 4) {     // (not even instantiated for the 256 x 64 tile)
@@ -568,10 +580,16 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false, false, true>), grid, block, lds, s, p);
       }
     }
-  } else if (use_glds) {     // LDS-DMA staging, double-buffered (default)
+  } else if (use_glds && host_uni) {     // LDS-DMA staging, double-buffered, uniform-tap address path only (the usual case)
+    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, false, true>), grid, block, lds, s, p);
+    else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, false, true>), grid, block, lds, s, p);
+  } else if (use_glds) {     // LDS-DMA staging, both address paths compiled in (stem, odd channel counts)
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true>), grid, block, lds, s, p);
-  } else {            // register staging, single buffer (DPA_CONV_STAGING=reg: A/B reference)
+  } else if (host_uni) {     // register staging, single buffer (short reductions), uniform-tap path only
+    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, false, true>), grid, block, lds, s, p);
+    else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false, false, false, true>), grid, block, lds, s, p);
+  } else {            // register staging, single buffer
     if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false>), grid, block, lds, s, p);
   }
