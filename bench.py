@@ -169,7 +169,7 @@ def main():
                    "--comm", "torch", "--no-secondary"] + (["--graph"] if args.graph else [])
             entry = {"dtype": dt, "fp32_mode": mode if dt == "fp32" else None}
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)   # bounded: 2 children x 150 s + the headline stay far below the driver's 600 s
                 lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 d = json.loads(lines[-1])
                 entry.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],

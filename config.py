@@ -81,7 +81,7 @@ COMPAT_EPOCH_ORDER = _env("COMPAT_EPOCH_ORDER", False, bool)  # reproduce the re
 RENDEZVOUS_TIMEOUT_S = _env("RENDEZVOUS_TIMEOUT_S", 300.0, float)
 COLLECTIVE_TIMEOUT_S = _env("COLLECTIVE_TIMEOUT_S", 600.0, float)
 CHECK_SYNC_EVERY = _env("CHECK_SYNC_EVERY", 0, int)   # >0: all-rank parameter checksum every N epochs
-SYNTHETIC_DATA = _env("SYNTHETIC_DATA", True, bool)  # generate a deterministic synthetic MNIST under -d when the IDX files are absent
+SYNTHETIC_DATA = _env("SYNTHETIC_DATA", False, bool)  # opt-in: when the real IDX files are absent under -d/MNIST/raw, train on a deterministic synthetic stand-in kept under -d/MNIST-synthetic/raw (default: fail like the reference's download=False)
 # RCCL/NCCL transport knobs for multi-node runs, exported by the launcher when set (the reference keeps a commented
 # NCCL_IB_DISABLE line, main.py:131): e.g. DPA_NCCL_ENV="NCCL_IB_DISABLE=1,NCCL_SOCKET_IFNAME=eth0"
 NCCL_ENV = _env("NCCL_ENV", '')

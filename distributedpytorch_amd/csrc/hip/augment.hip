@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) augment_mnist_kernel(const unsigned char*
   }
 }
 
-DPA_API void dpa_augment_mnist(const unsigned char* images, const long long* labels, const int* index, void* out,
+DPA_API int dpa_augment_mnist(const unsigned char* images, const long long* labels, const int* index, void* out,
                                long long* labels_out, const AugP* pp, int dtype, hipStream_t s) {
   AugP p = *pp;
   int ychunks = 2048 / (p.B > 0 ? p.B : 1);
@@ -99,5 +99,6 @@ DPA_API void dpa_augment_mnist(const unsigned char* images, const long long* lab
   dim3 grid(p.B, ychunks);
   if (dtype == 1) hipLaunchKernelGGL(augment_mnist_kernel<bf16_t>, grid, dim3(256), 0, s, images, labels, index, (bf16_t*)out, labels_out, p);
   else            hipLaunchKernelGGL(augment_mnist_kernel<float>, grid, dim3(256), 0, s, images, labels, index, (float*)out, labels_out, p);
+  return dpa_launch_rc();
 }
 DPA_API int dpa_aug_params_size() { return (int)sizeof(AugP); }

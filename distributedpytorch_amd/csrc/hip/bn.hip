@@ -16,7 +16,8 @@
 
 template <typename T>
 __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, long long M, int C, int cs,
-                                                       float* __restrict__ slab, int rowsPerBlock) {
+                                                       float* __restrict__ slab, int rowsPerBlock,
+                                                       const float* __restrict__ shift) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[2][256][VEC > 4 ? 9 : 5];
   const int cpr = C / VEC;
@@ -27,15 +28,19 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
   const long long r0 = (long long)blockIdx.x * rowsPerBlock;
   long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
   for (int cb = 0; cb < cpr; cb += colsPerPass) {
-    float s[VEC], q[VEC];
+    float s[VEC], q[VEC], c0[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; c0[e] = 0.f; }
     const int cc = cb + col;
     if (cc < cpr && rl < rowLanes) {
+      if (shift) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) c0[e] = shift[cc * VEC + e];
+      }
       for (long long r = r0 + rl; r < r1; r += rowLanes) {
         Vec16<T> v; v.load(x + r * cs + (long long)cc * VEC);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { const float f = v.get(e); s[e] += f; q[e] += f * f; }
+        for (int e = 0; e < VEC; ++e) { const float f = v.get(e) - c0[e]; s[e] += f; q[e] += f * f; }
       }
     }
 #pragma unroll
@@ -69,15 +74,23 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict
                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                                          long long* __restrict__ nbt, float momentum, float eps,
                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                         float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                                         float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                                         float* __restrict__ stat_shift) {
+  // Shifted-data variance: the slab holds sum(x - c) and sum((x - c)^2) about a per-channel shift c (the previous
+  // step's batch mean, kept in `stat_shift` and refreshed here), so var = E[(x-c)^2] - (E[x-c])^2 subtracts two SMALL
+  // numbers even when |mean| >> std (post-ReLU inputs of DenseNet's pre-activation BN, the inception stem) - the
+  // plain E[x^2] - mean^2 in fp32 loses every digit of the variance there (mean 100, std 0.1: 10000.01 - 10000).
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   float s = 0.f, q = 0.f;
   for (int r = 0; r < rows; ++r) { s += slab[((size_t)r * 2) * C + c]; q += slab[((size_t)r * 2 + 1) * C + c]; }
-  const float mean = s / count;
-  float var = q / count - mean * mean;
+  const float c0 = stat_shift ? stat_shift[c] : 0.f;
+  const float dm = s / count;
+  const float mean = c0 + dm;
+  float var = q / count - dm * dm;
   if (var < 0.f) var = 0.f;
+  if (stat_shift) stat_shift[c] = mean;
   const float invstd = rsqrtf(var + eps);
   mean_out[c] = mean; invstd_out[c] = invstd;
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -303,39 +316,44 @@ static const float* shrink_slab(const float* slab, int* rows, int C, float* scra
 DPA_API int dpa_bn_slab_rows(long long M) { int nb; rows_per_block(M, &nb); return nb; }
 
 // scratch: >= ROWS_L2*2*C floats.  slab: [rows][2][C]
-DPA_API void dpa_bn_stats(const void* x, int dtype, long long M, int C, int cs, float* slab, hipStream_t s) {
+DPA_API int dpa_bn_stats(const void* x, int dtype, long long M, int C, int cs, float* slab, const float* shift, hipStream_t s) {
   int nb; const int rpb = rows_per_block(M, &nb);
-  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rpb);
-  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rpb);
+  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rpb, shift);
+  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rpb, shift);
+  return dpa_launch_rc();
 }
 // Same slab, caller-chosen row blocking (the split-K conv path rebuilds the stats its fused epilogue would have written).
-DPA_API void dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
-                               int nblocks, hipStream_t s) {
-  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rowsPerBlock);
-  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblocks), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rowsPerBlock);
+DPA_API int dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
+                               int nblocks, const float* shift, hipStream_t s) {
+  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rowsPerBlock, shift);
+  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblocks), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rowsPerBlock, shift);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_bn_finalize(const float* slab, int rows, int C, long long count, const float* gamma, const float* beta,
+DPA_API int dpa_bn_finalize(const float* slab, int rows, int C, long long count, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
                              float* mean_out, float* invstd_out, float* scale_out, float* shift_out, float* scratch,
-                             hipStream_t s) {
+                             float* stat_shift, hipStream_t s) {
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, (float)count, gamma, beta,
-                     running_mean, running_var, nbt, momentum, eps, mean_out, invstd_out, scale_out, shift_out);
+                     running_mean, running_var, nbt, momentum, eps, mean_out, invstd_out, scale_out, shift_out, stat_shift);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+DPA_API int dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                 float* scale_out, float* shift_out, hipStream_t s) {
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, gamma, beta, rm, rv, eps, scale_out, shift_out);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
+DPA_API int dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
                           int y_cs, long long M, int C, int relu, int dtype, hipStream_t s) {
   int nb; const int rpb = ew_rows_per_block(M, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
                                      (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb);
   else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
                                      (const float*)res, r_cs, (float*)y, y_cs, M, C, relu, rpb);
+  return dpa_launch_rc();
 }
 // slab: >= dpa_bn_slab_rows(M)*2*C floats; scratch >= ROWS_L2*2*C; sums: 2*C floats; coef: 3*C floats (for bn_bwd_dx)
-DPA_API void dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, const void* x, int x_cs, const float* mean,
+DPA_API int dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, const void* x, int x_cs, const float* mean,
                                const float* invstd, const float* gamma, long long M, int C, float* slab, float* scratch,
                                float* dgamma, float* dbeta, float* sums, float* coef, int accumulate, int dtype,
                                hipStream_t s, const float* mscale, const float* mshift) {
@@ -348,14 +366,16 @@ DPA_API void dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, con
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
                      mean, invstd, gamma, 1.0f / (float)M, coef);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
+DPA_API int dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
                            long long M, int C, int dtype, hipStream_t s, const float* mscale, const float* mshift) {
   int nb; const int rpb = ew_rows_per_block(M, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
                                      (const bf16_t*)x, x_cs, coef, (bf16_t*)dx, dx_cs, M, C, rpb, mscale, mshift);
   else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, dz_cs,
                                      (const float*)x, x_cs, coef, (float*)dx, dx_cs, M, C, rpb, mscale, mshift);
+  return dpa_launch_rc();
 }
 
 // Per-channel column sum of a tall activation (conv bias gradients): stats slab -> fixed-order reduce.
@@ -367,10 +387,12 @@ __global__ void __launch_bounds__(64) slab_colsum_finalize_kernel(const float* _
   for (int r = 0; r < rows; ++r) s += slab[((size_t)r * 2) * C + c];
   out[c] = accumulate ? out[c] + s : s;
 }
-DPA_API void dpa_colsum_tall(const void* x, int dtype, long long M, int C, int cs, float* slab, float* scratch, float* out,
+DPA_API int dpa_colsum_tall(const void* x, int dtype, long long M, int C, int cs, float* slab, float* scratch, float* out,
                              int accumulate, hipStream_t s) {
-  dpa_bn_stats(x, dtype, M, C, cs, slab, s);
+  const int rc0 = dpa_bn_stats(x, dtype, M, C, cs, slab, nullptr, s);
+  if (rc0) return rc0;
   int rows = dpa_bn_slab_rows(M);
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
   hipLaunchKernelGGL(slab_colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, out, accumulate);
+  return dpa_launch_rc();
 }

@@ -66,6 +66,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Every DPA_API entry point that launches kernels returns this: 0, or the hipError_t of a rejected launch (too much
+// dynamic LDS, an oversize grid, ...).  Outputs are torch.empty buffers, so a launch that silently did not happen would
+// train on uninitialised memory; the Python wrappers raise on a non-zero status (ops/native.py).
+static inline int dpa_launch_rc() { return (int)hipGetLastError(); }
+
 // Memory-bound grid sizing: cap at 256 CUs x 8 blocks and grid-stride the rest.
 static inline int dpa_grid(long long work_items, int block) {
   long long g = (work_items + block - 1) / block;

@@ -35,6 +35,8 @@ struct ConvParams {
   const float* bias; // [dC] or null
   float* stats;      // [gridM][2][dC] per-block (sum, sumsq) slab of the fp32 accumulators, or null
   const void* addend; // optional tensor with dst geometry added in the epilogue (dgrad accumulation) or null
+  const float* stats_shift; // [dC] or null: the slab holds sum(v - c), sum((v - c)^2) about this per-channel shift c
+                            // (shifted-data variance: no cancellation when |mean| >> std, see bn_finalize_kernel)
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;

@@ -334,6 +334,12 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
     const int col = n0 + wn * WCOLS + j * 16 + fr;
     bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
   }
+  float cj[TN];                                // statistics shift of this lane's columns
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WCOLS + j * 16 + fr;
+    cj[j] = (p.stats && p.stats_shift && col < p.dC) ? p.stats_shift[col] : 0.f;
+  }
   constexpr int LPR = WCOLS / VEC;             // lanes per output row (16-B chunks per row)
   constexpr int RPI = 64 / LPR;                // rows per store instruction
 #pragma unroll
@@ -394,6 +400,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][j][e] + bj[j];
             if (sizeof(T) == 2) v = bf2f(f2bf(v));   // statistics of the values as stored
+            v -= cj[j];
             csum[j] += v; csq[j] += v * v;
           }
       } else {
@@ -404,6 +411,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
             const int m = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
             float v = acc[i][j][e] + bj[j];
             if (sizeof(T) == 2) v = bf2f(f2bf(v));
+            v -= cj[j];
             if (m >= p.M) v = 0.f;
             csum[j] += v; csq[j] += v * v;
           }
@@ -433,8 +441,8 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
   }
 }
 
-extern "C" void dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
-                                  int nblocks, hipStream_t s);
+extern "C" int dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
+                                 int nblocks, const float* shift, hipStream_t s);
 
 // Sum the split-K partials and apply the epilogue the conv kernel skipped: bias, residual addend, ReLU, store as T.
 template <typename T>
@@ -474,9 +482,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p) 
   }
 }
 
-// Per-device split-K workspace, allocated on first use (in the warm-up iterations, before any graph capture).
-static const size_t kSplitWsBytes = 64ull << 20;
-static float* splitk_workspace() {
+// Per-device split-K workspace.  Allocated by dpa_init_workspaces() when the library is loaded - not inside a launch
+// path, which a hipGraph capture may be recording; if it is missing while the stream is being captured the launch
+// runs unsplit.  DPA_SPLITK_WS_MB sizes it (default 256 MiB of the 288 GB; a problem whose partial sums do not fit
+// takes fewer splits).
+static size_t splitk_ws_bytes() {
+  static const size_t v = [] { const char* e = getenv("DPA_SPLITK_WS_MB"); long mb = e ? atol(e) : 0; return (size_t)(mb > 0 ? mb : 256) << 20; }();
+  return v;
+}
+static float* splitk_workspace(hipStream_t s) {
   static std::mutex mu;
   static std::map<int, float*> ws;
   std::lock_guard<std::mutex> lk(mu);
@@ -484,11 +498,20 @@ static float* splitk_workspace() {
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   auto it = ws.find(dev);
   if (it == ws.end()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
     float* ptr = nullptr;
-    if (hipMalloc((void**)&ptr, kSplitWsBytes) != hipSuccess) ptr = nullptr;
+    if (hipMalloc((void**)&ptr, splitk_ws_bytes()) != hipSuccess) { (void)hipGetLastError(); ptr = nullptr; }
     it = ws.emplace(dev, ptr).first;
   }
   return it->second;
+}
+extern "C" int dpa_init_ce_workspace();
+// Called once per device by ops/native.py right after the library is loaded on a machine with a GPU.
+DPA_API int dpa_init_workspaces() {
+  const int a = splitk_workspace(nullptr) ? 0 : 1;
+  const int b = dpa_init_ce_workspace();
+  return a | (b << 1);
 }
 
 // fp32 arithmetic mode of the convolution kernels (fprop / dgrad here, wgrad in conv_wgrad.hip): 0 = exact fp32 MFMA,
@@ -544,8 +567,8 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
     int want = slots / ntiles;
     if (want > nkt / 8) want = nkt / 8;
     const size_t need = (size_t)p.M * p.dC * sizeof(float);
-    while (want > 1 && need * want > kSplitWsBytes) --want;
-    float* ws = want > 1 ? splitk_workspace() : nullptr;
+    while (want > 1 && need * want > splitk_ws_bytes()) --want;
+    float* ws = want > 1 ? splitk_workspace(s) : nullptr;
     if (ws) {
       p.kt_per_split = (nkt + want - 1) / want;
       p.splitK = (nkt + p.kt_per_split - 1) / p.kt_per_split;
@@ -599,7 +622,7 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(rb), dim3(256), 0, s, p);
     if (p.stats)      // the fused-epilogue statistics, rebuilt from the stored output (one slab row per M-tile)
       dpa_bn_stats_rows(reinterpret_cast<const T*>(p.dst) + p.d_co, sizeof(T) == 2 ? 1 : 0, p.M, p.dC, p.d_cs, p.stats, BM,
-                        p.tilesM, s);
+                        p.tilesM, p.stats_shift, s);
   }
 }
 
@@ -715,7 +738,10 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
 // dtype: 0 = fp32, 1 = bf16.  Returns 0 on success, non-zero for an unsupported geometry.
 DPA_API int dpa_conv_igemm(ConvParams* p, int dtype, int dgrad, hipStream_t s) {
   ConvParams q = *p;
-  return dtype == 1 ? launch_conv<bf16_t>(q, dgrad, s) : launch_conv<float>(q, dgrad, s);
+  const int rc = dtype == 1 ? launch_conv<bf16_t>(q, dgrad, s) : launch_conv<float>(q, dgrad, s);
+  if (rc) return rc;                       // 1, 2: unsupported geometry (nothing was launched)
+  const int e = dpa_launch_rc();           // a rejected launch (LDS size, grid size, ...) must not pass silently
+  return e ? 1000 + e : 0;
 }
 // rows of the per-block stats slab a launch with these dims will write (tilesM of the chosen config)
 DPA_API int dpa_conv_stats_rows(int M, int dC, int dtype) {

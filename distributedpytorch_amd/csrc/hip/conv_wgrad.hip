@@ -360,7 +360,10 @@ static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_
 // workspace: fp32 scratch of at least dpa_conv_wgrad_workspace() floats, or null to force splitK = 1.
 DPA_API int dpa_conv_wgrad(WgradParams* p, float* grad, float* workspace, int dtype, hipStream_t s) {
   WgradParams q = *p;
-  return dtype == 1 ? wg_dispatch<bf16_t>(q, grad, workspace, s) : wg_dispatch<float>(q, grad, workspace, s);
+  const int rc = dtype == 1 ? wg_dispatch<bf16_t>(q, grad, workspace, s) : wg_dispatch<float>(q, grad, workspace, s);
+  if (rc) return rc;
+  const int e = dpa_launch_rc();
+  return e ? 1000 + e : 0;
 }
 // upper bound on workspace floats for a layer: split <= 1024 tiles-worth, i.e. <= ~1024*BM*BN + K*Ng
 DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {

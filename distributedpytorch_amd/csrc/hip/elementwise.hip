@@ -134,47 +134,56 @@ __global__ void rng_advance_kernel(unsigned long long* rng) { rng[1] += 1ull; }
     else            hipLaunchKernelGGL(kern<float>, dim3(grid_), dim3(256), 0, s, __VA_ARGS__);         \
   } while (0)
 
-DPA_API void dpa_relu_bwd(void* dy, int dy_cs, const void* y, int y_cs, long long M, int C, int dtype, hipStream_t s) {
+DPA_API int dpa_relu_bwd(void* dy, int dy_cs, const void* y, int y_cs, long long M, int C, int dtype, hipStream_t s) {
   const long long total = M * (C / (dtype == 1 ? 8 : 4));
   if (dtype == 1) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (bf16_t*)dy, dy_cs, (const bf16_t*)y, y_cs, M, C);
   else            hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (float*)dy, dy_cs, (const float*)y, y_cs, M, C);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_relu_fwd(const void* x, int x_cs, void* y, int y_cs, long long M, int C, int dtype, hipStream_t s) {
+DPA_API int dpa_relu_fwd(const void* x, int x_cs, void* y, int y_cs, long long M, int C, int dtype, hipStream_t s) {
   const long long total = M * (C / (dtype == 1 ? 8 : 4));
   if (dtype == 1) hipLaunchKernelGGL(relu_fwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, x_cs, (bf16_t*)y, y_cs, M, C);
   else            hipLaunchKernelGGL(relu_fwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)x, x_cs, (float*)y, y_cs, M, C);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_add(const void* a, int a_cs, const void* b, int b_cs, void* out, int o_cs, long long M, int C, int dtype,
+DPA_API int dpa_add(const void* a, int a_cs, const void* b, int b_cs, void* out, int o_cs, long long M, int C, int dtype,
                      hipStream_t s) {
   const long long total = M * (C / (dtype == 1 ? 8 : 4));
   if (dtype == 1) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)a, a_cs, (const bf16_t*)b, b_cs, (bf16_t*)out, o_cs, M, C);
   else            hipLaunchKernelGGL(add_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)a, a_cs, (const float*)b, b_cs, (float*)out, o_cs, M, C);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_copy(const void* a, int a_cs, void* out, int o_cs, long long M, int C, int dtype, hipStream_t s) {
+DPA_API int dpa_copy(const void* a, int a_cs, void* out, int o_cs, long long M, int C, int dtype, hipStream_t s) {
   const long long total = M * (C / (dtype == 1 ? 8 : 4));
   if (dtype == 1) hipLaunchKernelGGL(copy_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)a, a_cs, (bf16_t*)out, o_cs, M, C);
   else            hipLaunchKernelGGL(copy_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)a, a_cs, (float*)out, o_cs, M, C);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_dropout(const void* x, int x_cs, void* y, int y_cs, long long M, int C, float p,
+DPA_API int dpa_dropout(const void* x, int x_cs, void* y, int y_cs, long long M, int C, float p,
                          const unsigned long long* rng, unsigned long long layer_id, int dtype, hipStream_t s) {
   const long long total = M * (C / (dtype == 1 ? 8 : 4));
   if (dtype == 1) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, x_cs, (bf16_t*)y, y_cs, M, C, p, rng, layer_id);
   else            hipLaunchKernelGGL(dropout_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)x, x_cs, (float*)y, y_cs, M, C, p, rng, layer_id);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_rng_advance(unsigned long long* rng, hipStream_t s) {
+DPA_API int dpa_rng_advance(unsigned long long* rng, hipStream_t s) {
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, s, rng);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_transpose_krsc(const void* w, void* wt, int K, int RS, int C, int dtype, hipStream_t s) {
+DPA_API int dpa_transpose_krsc(const void* w, void* wt, int K, int RS, int C, int dtype, hipStream_t s) {
   const long long total = (long long)K * RS * C;
   if (dtype == 1) hipLaunchKernelGGL(transpose_krsc_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wt, K, RS, C);
   else            hipLaunchKernelGGL(transpose_krsc_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)w, (float*)wt, K, RS, C);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_colsum(const void* x, int cs, long long M, int C, float* out, int accumulate, int dtype, hipStream_t s) {
+DPA_API int dpa_colsum(const void* x, int cs, long long M, int C, float* out, int accumulate, int dtype, hipStream_t s) {
   const int grid = (C + 63) / 64;
   if (dtype == 1) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, cs, M, C, out, accumulate);
   else            hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, cs, M, C, out, accumulate);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_fill_f32(float* p, float v, long long n, hipStream_t s) {
-  if (n <= 0) return;
+DPA_API int dpa_fill_f32(float* p, float v, long long n, hipStream_t s) {
+  if (n <= 0) return 0;
   hipLaunchKernelGGL(fill_f32_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, p, v, n);
+  return dpa_launch_rc();
 }

@@ -160,38 +160,45 @@ __global__ void __launch_bounds__(64) ce_finish_kernel(const float* __restrict__
   }
 }
 
-static float* ce_partials(int need_floats) {      // per-device scratch, allocated on first use (before any graph capture)
-  static std::mutex mu;
-  static std::map<int, std::pair<float*, int>> ws;
-  std::lock_guard<std::mutex> lk(mu);
+// Per-device scratch for the multi-block variant.  Allocated by dpa_init_workspaces() when the library is loaded (never
+// inside a launch path that a hipGraph capture may be recording); a batch that outgrows it while the stream is being
+// captured takes the single-block kernel instead of allocating.
+static std::mutex ce_mu;
+static std::map<int, std::pair<float*, int>> ce_ws;
+static float* ce_partials(int need_floats, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(ce_mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  auto& e = ws[dev];
+  auto& e = ce_ws[dev];
   if (e.second < need_floats) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
     float* ptr = nullptr;
     const int cap = need_floats < 16384 ? 16384 : need_floats;
-    if (hipMalloc((void**)&ptr, (size_t)cap * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&ptr, (size_t)cap * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     e = {ptr, cap};         // (an outgrown buffer is left alone: earlier launches may still read it)
   }
   return e.first;
 }
+extern "C" int dpa_init_ce_workspace() { return ce_partials(16384, nullptr) ? 0 : 1; }
 
-DPA_API void dpa_ce_loss(const void* logits, int ld, const long long* labels, int N, int C, const float* class_w, int mode,
+DPA_API int dpa_ce_loss(const void* logits, int ld, const long long* labels, int N, int C, const float* class_w, int mode,
                          float gamma, float scale, int aux, void* dlogits, float* out, float* accum, int dtype, hipStream_t s) {
   if (mode != 1 && (long long)N * C >= (1 << 16) && N >= 64) {
     const int nb = (N + 15) / 16;
-    float* part = ce_partials(2 * nb);
+    float* part = ce_partials(2 * nb, s);
     if (part) {
       if (dtype == 1) hipLaunchKernelGGL(ce_rows_kernel<bf16_t>, dim3(nb), dim3(1024), 0, s, (const bf16_t*)logits, ld, labels, N, C,
                                          class_w, mode, gamma, scale, (bf16_t*)dlogits, part);
       else            hipLaunchKernelGGL(ce_rows_kernel<float>, dim3(nb), dim3(1024), 0, s, (const float*)logits, ld, labels, N, C,
                                          class_w, mode, gamma, scale, (float*)dlogits, part);
       hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, s, part, nb, N, scale, aux, out, accum);
-      return;
+      return dpa_launch_rc();
     }
   }
   if (dtype == 1) hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3(1), dim3(1024), 0, s, (const bf16_t*)logits, ld, labels, N, C,
                                      class_w, mode, gamma, scale, aux, (bf16_t*)dlogits, out, accum);
   else            hipLaunchKernelGGL(ce_loss_kernel<float>, dim3(1), dim3(1024), 0, s, (const float*)logits, ld, labels, N, C,
                                      class_w, mode, gamma, scale, aux, (float*)dlogits, out, accum);
+  return dpa_launch_rc();
 }

@@ -63,18 +63,39 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
                                                   const float* __restrict__ hyper, long long n) {
   const float lr = hyper[0], wd = hyper[4], mu = hyper[6], gs = hyper[7];
   const bool first = hyper[5] < 0.5f;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    float gr = g[i] * gs + wd * p[i];
-    float b = gr;
-    if (mu != 0.0f) {
-      b = first ? gr : mu * buf[i] + gr;
-      buf[i] = b;
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // 16 B per lane, like adam_kernel
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 pp = *reinterpret_cast<float4*>(p + i);
+    const float4 gg = *reinterpret_cast<const float4*>(g + i);
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mu != 0.0f && !first) bb = *reinterpret_cast<float4*>(buf + i);
+    float* pa = (float*)&pp; const float* ga = (const float*)&gg; float* ba = (float*)&bb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = ga[k] * gs + wd * pa[k];
+      const float b = (mu != 0.0f && !first) ? mu * ba[k] + gr : gr;
+      ba[k] = b;
+      pa[k] -= lr * b;
     }
-    float pj = p[i] - lr * b;
-    p[i] = pj;
-    if (p16) p16[i] = f2bf(pj);
+    *reinterpret_cast<float4*>(p + i) = pp;
+    if (mu != 0.0f) *reinterpret_cast<float4*>(buf + i) = bb;
+    if (p16) {
+      uint2 o;
+      o.x = (uint32_t)f2bf(pa[0]) | ((uint32_t)f2bf(pa[1]) << 16);
+      o.y = (uint32_t)f2bf(pa[2]) | ((uint32_t)f2bf(pa[3]) << 16);
+      *reinterpret_cast<uint2*>(p16 + i) = o;
+    }
+  }
+  if (i < n) {                                                                // tail (n not a multiple of 4)
+    for (long long j = i; j < n; ++j) {
+      const float gr = g[j] * gs + wd * p[j];
+      float b = gr;
+      if (mu != 0.0f) { b = first ? gr : mu * buf[j] + gr; buf[j] = b; }
+      const float pj = p[j] - lr * b;
+      p[j] = pj;
+      if (p16) p16[j] = f2bf(pj);
+    }
   }
 }
 
@@ -91,24 +112,29 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __rest
   for (; i < n; i += stride) d[i] = bf2f(s[i]);
 }
 
-DPA_API void dpa_adam_step(float* p, const float* g, float* m, float* v, bf16_t* p16, const float* hyper,
+DPA_API int dpa_adam_step(float* p, const float* g, float* m, float* v, bf16_t* p16, const float* hyper,
                            long long n, hipStream_t s) {
-  if (n <= 0) return;
+  if (n <= 0) return 0;
   hipLaunchKernelGGL(adam_kernel, dim3(dpa_grid((n + 3) / 4, 256)), dim3(256), 0, s, p, g, m, v, p16, hyper, n);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_sgd_step(float* p, const float* g, float* buf, bf16_t* p16, const float* hyper, long long n,
+DPA_API int dpa_sgd_step(float* p, const float* g, float* buf, bf16_t* p16, const float* hyper, long long n,
                           hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(sgd_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, p, g, buf, p16, hyper, n);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(dpa_grid((n + 3) / 4, 256)), dim3(256), 0, s, p, g, buf, p16, hyper, n);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_advance_step(float* hyper, hipStream_t s) {
+DPA_API int dpa_advance_step(float* hyper, hipStream_t s) {
   hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, hyper);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s) {
-  if (n <= 0) return;
+DPA_API int dpa_cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s) {
+  if (n <= 0) return 0;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, src, dst, n);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t s) {
-  if (n <= 0) return;
+DPA_API int dpa_cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t s) {
+  if (n <= 0) return 0;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(dpa_grid(n, 256)), dim3(256), 0, s, src, dst, n);
+  return dpa_launch_rc();
 }

@@ -269,20 +269,22 @@ __global__ void __launch_bounds__(256) adaptive_avgpool_bwd_kernel(const T* __re
     else            hipLaunchKernelGGL(kern<float>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
   } while (0)
 
-DPA_API void dpa_maxpool_fwd(const void* x, void* y, unsigned char* idx, const PoolP* pp, int dtype, hipStream_t s) {
+DPA_API int dpa_maxpool_fwd(const void* x, void* y, unsigned char* idx, const PoolP* pp, int dtype, hipStream_t s) {
   PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
   const long long total = (long long)p.N * p.Ho * p.Wo * (p.C / vec);
   if (dtype == 1) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, p);
   else            hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, idx, p);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, const PoolP* pp, int dy_cs, int dx_cs,
+DPA_API int dpa_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, const PoolP* pp, int dy_cs, int dx_cs,
                              int dtype, hipStream_t s) {
   PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
   const long long total = (long long)p.N * p.H * p.W * (p.C / vec);
   if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, p, dy_cs, dx_cs);
   else            hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, p, dy_cs, dx_cs);
+  return dpa_launch_rc();
 }
-DPA_API void dpa_avgpool_fwd(const void* x, void* y, const PoolP* pp, int adaptive, int dtype, hipStream_t s) {
+DPA_API int dpa_avgpool_fwd(const void* x, void* y, const PoolP* pp, int adaptive, int dtype, hipStream_t s) {
   PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
   const long long total = (long long)p.N * p.Ho * p.Wo * (p.C / vec);
   const int grid = dpa_grid(total, 256);
@@ -293,8 +295,9 @@ DPA_API void dpa_avgpool_fwd(const void* x, void* y, const PoolP* pp, int adapti
     if (dtype == 1) hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, p);
     else            hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, p);
   }
+  return dpa_launch_rc();
 }
-DPA_API void dpa_avgpool_bwd(const void* dy, void* dx, const PoolP* pp, int dy_cs, int dx_cs, int adaptive, int dtype,
+DPA_API int dpa_avgpool_bwd(const void* dy, void* dx, const PoolP* pp, int dy_cs, int dx_cs, int adaptive, int dtype,
                              hipStream_t s) {
   PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
   const long long total = (long long)p.N * p.H * p.W * (p.C / vec);
@@ -306,5 +309,6 @@ DPA_API void dpa_avgpool_bwd(const void* dy, void* dx, const PoolP* pp, int dy_c
     if (dtype == 1) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, p, dy_cs, dx_cs);
     else            hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (float*)dx, p, dy_cs, dx_cs);
   }
+  return dpa_launch_rc();
 }
 DPA_API int dpa_pool_params_size() { return (int)sizeof(PoolP); }

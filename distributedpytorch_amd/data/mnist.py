@@ -51,18 +51,39 @@ def write_idx(path, arr: np.ndarray):
 
 
 def raw_dir(root):
+    """Where torchvision.datasets.MNIST keeps the REAL files (/root/reference/dataloader.py:92-93)."""
     return os.path.join(root, "MNIST", "raw")
 
 
+def synthetic_dir(root):
+    """Where the synthetic stand-in lives: never under MNIST/raw, so it cannot be taken for the real dataset by a later
+    run or by torchvision."""
+    return os.path.join(root, "MNIST-synthetic", "raw")
+
+
+def _have(d):
+    return all(os.path.exists(os.path.join(d, f)) for pair in FILES.values() for f in pair)
+
+
 def have_mnist(root):
-    return all(os.path.exists(os.path.join(raw_dir(root), f)) for pair in FILES.values() for f in pair)
+    return _have(raw_dir(root))
+
+
+def have_synthetic(root):
+    """Complete synthetic set: the four files AND the marker the writer creates last."""
+    return _have(synthetic_dir(root)) and os.path.exists(os.path.join(synthetic_dir(root), ".complete"))
 
 
 def generate_synthetic_mnist(root, n_train=60000, n_test=10000, seed=1234):
     """Deterministic MNIST-shaped stand-in (there is no network to fetch the real files): ten smooth stroke
     prototypes, one per class, with per-sample shift, scale jitter and noise, written as the four IDX files
-    torchvision.datasets.MNIST expects under <root>/MNIST/raw."""
-    os.makedirs(raw_dir(root), exist_ok=True)
+    torchvision.datasets.MNIST uses, under <root>/MNIST-synthetic/raw (NOT MNIST/raw: see synthetic_dir).  Each file is
+    written under a temporary name and renamed; the `.complete` marker comes last, and readers gate on it."""
+    out_dir = synthetic_dir(root)
+    os.makedirs(out_dir, exist_ok=True)
+    marker = os.path.join(out_dir, ".complete")
+    if os.path.exists(marker):
+        os.remove(marker)
     rng = np.random.RandomState(seed)
     protos = []
     yy, xx = np.mgrid[0:28, 0:28].astype(np.float32)
@@ -89,11 +110,12 @@ def generate_synthetic_mnist(root, n_train=60000, n_test=10000, seed=1234):
 
     tr_x, tr_y = make(n_train, np.random.RandomState(seed + 1))
     te_x, te_y = make(n_test, np.random.RandomState(seed + 2))
-    write_idx(os.path.join(raw_dir(root), FILES["train"][0]), tr_x)
-    write_idx(os.path.join(raw_dir(root), FILES["train"][1]), tr_y)
-    write_idx(os.path.join(raw_dir(root), FILES["test"][0]), te_x)
-    write_idx(os.path.join(raw_dir(root), FILES["test"][1]), te_y)
-    logging.info(f"synthetic MNIST written to {raw_dir(root)} ({n_train} train / {n_test} test)")
+    for name, arr in ((FILES["train"][0], tr_x), (FILES["train"][1], tr_y), (FILES["test"][0], te_x), (FILES["test"][1], te_y)):
+        tmp = os.path.join(out_dir, f".{name}.tmp{os.getpid()}")
+        write_idx(tmp, arr)
+        os.replace(tmp, os.path.join(out_dir, name))
+    open(marker, "w").close()
+    logging.warning(f"SYNTHETIC MNIST written to {out_dir} ({n_train} train / {n_test} test): NOT the real dataset")
 
 
 # ------------------------------------------------------------------------------------------------ dataset
@@ -140,7 +162,7 @@ class BatchIterator:
 
 class MNIST:
     def __init__(self, dataPath, batchSize, dataDim, worldSize, rank, gpu, device=None, dtype=torch.float32, debug=False,
-                 seed=1234, synthetic_ok=True):
+                 seed=1234, synthetic_ok=False):
         self.dataPath, self.batchSize, self.dataDim = dataPath, batchSize, dataDim
         self.worldSize, self.rank, self.gpu = worldSize, rank, gpu
         self.device = device if device is not None else torch.device("cuda", gpu) if gpu >= 0 else torch.device("cpu")
@@ -160,22 +182,25 @@ class MNIST:
             logging.info(f"Number of testing examples: {len(self.data['test'])}")
 
     def loadDataset(self):
-        if not have_mnist(self.dataPath):
-            if not self.synthetic_ok:
-                raise FileNotFoundError(f"MNIST IDX files not found under {raw_dir(self.dataPath)}")
-            # one writer per node; the others wait for the files (same deterministic content on every node)
-            marker = os.path.join(raw_dir(self.dataPath), ".complete")
-            if self.gpu <= 0:
+        if have_mnist(self.dataPath):
+            raw = raw_dir(self.dataPath)
+        elif not self.synthetic_ok:
+            # the reference's behaviour (download=False): a mistyped -d must not silently train on something else
+            raise FileNotFoundError(f"MNIST IDX files not found under {raw_dir(self.dataPath)} "
+                                    f"(DPA_SYNTHETIC_DATA=1 trains on a generated stand-in instead)")
+        else:
+            # opted in: one writer per node (local rank 0), EVERY rank - the writer included - gates on the marker
+            if not have_synthetic(self.dataPath) and self.gpu <= 0:
                 generate_synthetic_mnist(self.dataPath, seed=self.seed)
-                open(marker, "w").close()
-            else:
-                import time
-                t0 = time.time()
-                while not os.path.exists(marker):
-                    if time.time() - t0 > 600:
-                        raise TimeoutError("timed out waiting for the synthetic MNIST files")
-                    time.sleep(0.2)
-        raw = raw_dir(self.dataPath)
+            import time
+            t0 = time.time()
+            while not have_synthetic(self.dataPath):
+                if time.time() - t0 > 600:
+                    raise TimeoutError("timed out waiting for the synthetic MNIST files")
+                time.sleep(0.2)
+            raw = synthetic_dir(self.dataPath)
+            if self.gpu <= 0:
+                logging.warning(f"training on SYNTHETIC digits from {raw}: accuracies are not MNIST accuracies")
         tr_x = torch.from_numpy(read_idx(os.path.join(raw, FILES["train"][0])))
         tr_y = torch.from_numpy(read_idx(os.path.join(raw, FILES["train"][1]))).long()
         te_x = torch.from_numpy(read_idx(os.path.join(raw, FILES["test"][0])))

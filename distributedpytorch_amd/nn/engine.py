@@ -77,6 +77,7 @@ class ParamStore:
         self.buffers: List[ParamSpec] = []
         self.entries: List[tuple] = []          # state_dict order: ('param'|'buffer'|'nbt', spec)
         self._init_values = {}
+        self.aux_tensors: List[torch.Tensor] = []   # per-layer persistent scratch that carries state between steps
         self.p = self.g = self.p16 = self.b = self.nbt = None
         self.p_size = self.b_size = 0
         self.n_nbt = 0

@@ -79,7 +79,7 @@ class Conv2d:
         return (ops.out_size(h, self.ksize[0], self.stride[0], self.padding[0]),
                 ops.out_size(w, self.ksize[1], self.stride[1], self.padding[1]))
 
-    def forward_raw(self, ctx: Context, x: torch.Tensor, out=None, relu=False, stats=None):
+    def forward_raw(self, ctx: Context, x: torch.Tensor, out=None, relu=False, stats=None, stats_shift=None):
         n, h, w, _ = x.shape
         ho, wo = self.out_hw(h, w)
         if out is None:
@@ -88,9 +88,9 @@ class Conv2d:
         w = self.store.cview(self.w)
         if self._as_gemm(x):      # whole-map 'valid' kernel = plain GEMM over the flattened (h, w, c) features
             ops.conv_fprop(x.view(n, 1, 1, -1), w.view(w.shape[0], 1, 1, -1), out, (1, 1), (0, 0), bias=bias, relu=relu,
-                           stats=stats)
+                           stats=stats, stats_shift=stats_shift)
         else:
-            ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats)
+            ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats, stats_shift=stats_shift)
         return out
 
     def _as_gemm(self, x: torch.Tensor) -> bool:
@@ -184,14 +184,18 @@ class BatchNorm2d:
         self.rv = store.add_buffer(f"{name}.running_var", c, 1.0)
         self.nbt = store.add_nbt(f"{name}.num_batches_tracked")
         self.trainable = trainable
-        self._aux = None
+        # persistent per-layer fp32 vectors: mean, invstd, scale, shift, sums[2], coef[3], statistics shift
+        self._aux = torch.zeros(10, pad_to(c), device=store.device)
+        store.aux_tensors.append(self._aux)      # (hipGraph capture snapshots / restores these around its warm-up)
 
     def aux(self, device):
-        """Persistent per-layer fp32 vectors: mean, invstd, scale, shift, sums[2], coef[3]."""
-        if self._aux is None:
-            cp = pad_to(self.c)
-            self._aux = torch.zeros(9, cp, device=device)
         return self._aux
+
+    def stat_shift(self, ctx: Context):
+        """Per-channel shift c of the training statistics (a[9] = the previous step's batch mean; 0 before the first
+        step): the conv epilogue / bn_stats accumulate sum(x-c), sum((x-c)^2), so from the second step on the variance
+        does not cancel when |mean| >> std (E[x^2] - mean^2 in fp32)."""
+        return self.aux(ctx.device)[9] if ctx.training else None
 
     def coeffs(self, ctx: Context, slab, count):
         """Finalize batch statistics (train) or fold running statistics (eval) into (scale, shift)."""
@@ -199,7 +203,8 @@ class BatchNorm2d:
         a = self.aux(ctx.device)
         if ctx.training:
             ops.bn_finalize(slab, count, st.view(self.gamma), st.view(self.beta), st.bview(self.rm), st.bview(self.rv),
-                            st.nbt[self.nbt: self.nbt + 1], self.momentum, self.eps, a[0], a[1], a[2], a[3])
+                            st.nbt[self.nbt: self.nbt + 1], self.momentum, self.eps, a[0], a[1], a[2], a[3],
+                            stat_shift=a[9])
         else:
             ops.bn_eval_coeffs(st.view(self.gamma), st.view(self.beta), st.bview(self.rm), st.bview(self.rv), self.eps,
                                a[2], a[3])
@@ -240,7 +245,7 @@ class ConvBNAct:
         ho, wo = conv.out_hw(h, w)
         m, cp = n * ho * wo, pad_to(conv.cout)
         slab = _stats_slab(ctx, m, cp, True) if ctx.training else None
-        z = conv.forward_raw(ctx, x.data, stats=slab)
+        z = conv.forward_raw(ctx, x.data, stats=slab, stats_shift=bn.stat_shift(ctx))
         a = bn.coeffs(ctx, slab, m)
         if out is None:
             out = ctx.empty((n, ho, wo, cp))
@@ -273,7 +278,7 @@ class BNAct:
         slab = None
         if ctx.training:
             slab = _stats_slab(ctx, m, c, False)
-            ops.bn_stats(x.data, slab)
+            ops.bn_stats(x.data, slab, shift=bn.stat_shift(ctx))
         a = bn.coeffs(ctx, slab, m)
         if out is None:
             out = ctx.empty((n, h, w, c))

@@ -61,12 +61,16 @@ class ArenaOptimizer:
 
     # ------------------------------------------------------------------ torch.optim-compatible state
     def state_dict(self):
+        # The reference builds the optimizer over model.parameters() - ALL of them, frozen ones included
+        # (/root/reference/classif.py:124, utils.py:107-110) - so `params` indexes every parameter in registration
+        # order and `state` holds entries only for those that received gradients (the trainable ones).
         st = self.store
-        trainable = [p for p in st.params if p.trainable]
         state = {}
         step = float(self.hyper[STEP].item())
         if step > 0:
-            for i, spec in enumerate(trainable):
+            for i, spec in enumerate(st.params):
+                if not spec.trainable:
+                    continue
                 sl = slice(spec.offset, spec.offset + spec.numel)
                 if self.kind == "adam":
                     state[i] = {"step": torch.tensor(step, dtype=torch.float32),
@@ -83,20 +87,20 @@ class ArenaOptimizer:
             group = {"lr": lr, "momentum": self.defaults["momentum"], "dampening": 0, "weight_decay":
                      self.defaults["weight_decay"], "nesterov": False, "maximize": False, "foreach": None,
                      "differentiable": False, "fused": None, "initial_lr": self.base_lr}
-        group["params"] = list(range(len(trainable)))
+        group["params"] = list(range(len(st.params)))
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         st = self.store
-        trainable = [p for p in st.params if p.trainable]
         group = sd["param_groups"][0]
-        if len(group["params"]) != len(trainable):
-            raise ValueError("optimizer state_dict has a different number of parameters")
+        if len(group["params"]) != len(st.params):
+            raise ValueError(f"optimizer state_dict covers {len(group['params'])} parameters, the model has "
+                             f"{len(st.params)}")
         self.set_lr(float(group["lr"]))
         step = 0.0
-        for i, spec in enumerate(trainable):
+        for i, spec in enumerate(st.params):
             s = sd["state"].get(i)
-            if s is None:
+            if s is None or not spec.trainable:
                 continue
             sl = slice(spec.offset, spec.offset + spec.numel)
             if self.kind == "adam":

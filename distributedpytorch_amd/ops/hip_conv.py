@@ -32,9 +32,9 @@ def out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None):
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats: fp32 [rows, 2, Cout] slab written with per-block
-    (sum, sumsq) of the stored outputs; rows = stats_rows(M, Cout)."""
+    (sum, sumsq) of the stored outputs minus the per-channel `stats_shift` (0 if None); rows = stats_rows(M, Cout)."""
     lib = native.hip_lib()
     sh, sw = stride
     ph, pw = pad
@@ -43,6 +43,7 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     p.bias = native.ptr(bias)
     p.stats = native.ptr(stats)
     p.addend = native.ptr(addend)
+    p.stats_shift = native.ptr(stats_shift)
     p.sN, p.sH, p.sW, p.sC = x.shape
     p.s_cs, p.s_co = _check_nhwc(x, "x"), 0
     p.dH, p.dW, p.dC = y.shape[1], y.shape[2], y.shape[3]
@@ -68,7 +69,7 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None):
     ph, pw = pad
     p = ConvParams()
     p.src, p.wgt, p.dst = VP(dy.data_ptr()), VP(wt.data_ptr()), VP(dx.data_ptr())
-    p.bias, p.stats, p.addend = VP(0), VP(0), native.ptr(addend)
+    p.bias, p.stats, p.addend, p.stats_shift = VP(0), VP(0), native.ptr(addend), VP(0)
     p.sN, p.sH, p.sW, p.sC = dy.shape
     p.s_cs, p.s_co = _check_nhwc(dy, "dy"), 0
     p.dH, p.dW, p.dC = dx.shape[1], dx.shape[2], dx.shape[3]

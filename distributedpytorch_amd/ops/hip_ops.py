@@ -62,21 +62,21 @@ def bn_slab_rows(m):
     return int(_lib().dpa_bn_slab_rows(I64(m)))
 
 
-def bn_stats(x, slab):
+def bn_stats(x, slab, shift=None):
     m, c, cs = _mc(x)
     assert slab.numel() >= bn_slab_rows(m) * 2 * c
-    _lib().dpa_bn_stats(ptr(x), _DT[x.dtype], I64(m), c, cs, ptr(slab), stream_ptr())
+    _lib().dpa_bn_stats(ptr(x), _DT[x.dtype], I64(m), c, cs, ptr(slab), ptr(shift), stream_ptr())
     return slab
 
 
 def bn_finalize(slab, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift,
-                scratch=None):
+                scratch=None, stat_shift=None):
     rows, c = slab.shape[0], slab.shape[2]
     if scratch is None:
         scratch = _scratch_f32(slab.device, ROWS_L2 * 2 * c, "bn")
     _lib().dpa_bn_finalize(ptr(slab), rows, c, I64(count), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                            ptr(nbt), F32(momentum), F32(eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                           ptr(scratch), stream_ptr())
+                           ptr(scratch), ptr(stat_shift), stream_ptr())
 
 
 def bn_eval_coeffs(gamma, beta, rm, rv, eps, scale, shift):

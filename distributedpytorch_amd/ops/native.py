@@ -31,7 +31,7 @@ class FastDiv(ctypes.Structure):
 
 class ConvParams(ctypes.Structure):
     _fields_ = [
-        ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP),
+        ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP), ("stats_shift", VP),
         ("sN", I32), ("sH", I32), ("sW", I32), ("sC", I32), ("s_cs", I32), ("s_co", I32),
         ("dH", I32), ("dW", I32), ("dC", I32), ("d_cs", I32), ("d_co", I32),
         ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),
@@ -58,6 +58,41 @@ def lib_path(name: str) -> str:
     return os.path.join(_LIBDIR, name)
 
 
+# entry points whose int return value is NOT a launch status (sizes, counts, modes) or is checked by its own caller
+_NOT_LAUNCH = {"dpa_conv_params_size", "dpa_wgrad_params_size", "dpa_pool_params_size", "dpa_aug_params_size",
+               "dpa_bn_slab_rows", "dpa_conv_stats_rows", "dpa_conv_wgrad_workspace", "dpa_get_fp32_mode",
+               "dpa_set_fp32_mode", "dpa_conv_igemm", "dpa_conv_wgrad", "dpa_init_workspaces"}
+
+
+class KernelLaunchError(RuntimeError):
+    pass
+
+
+class _CheckedLib:
+    """The kernel library with every launching entry point's status checked: each DPA_API launcher returns
+    hipGetLastError() (csrc/hip/common.h: dpa_launch_rc), and a rejected launch - too much dynamic LDS, an oversize
+    grid - raises here instead of leaving a torch.empty output uninitialised."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._lib, name)
+            if name in _NOT_LAUNCH:
+                fn = raw
+            else:
+                def fn(*args, _raw=raw, _name=name):
+                    rc = _raw(*args)
+                    if rc:
+                        raise KernelLaunchError(f"{_name}: kernel launch failed with hipError_t {rc}")
+                    return 0
+            self._cache[name] = fn
+        return fn
+
+
 def hip_lib():
     """The HIP kernel library; raises if it has not been built (python -m distributedpytorch_amd.csrc.build)."""
     global _hip
@@ -76,7 +111,13 @@ def hip_lib():
             raise RuntimeError("WgradParams ABI mismatch between ops/native.py and conv_wgrad.hip")
         lib.dpa_conv_wgrad_workspace.restype = I64
         lib.dpa_get_fp32_mode.restype = I32
-        _hip = lib
+        if torch.cuda.is_available():
+            # the per-device scratch of the split-K and multi-block-loss paths: allocated here, never inside a launch
+            # path (a hipGraph capture must not see a hipMalloc)
+            rc = lib.dpa_init_workspaces()
+            if rc:
+                raise RuntimeError(f"dpa_init_workspaces failed (rc={rc}): cannot allocate the kernel scratch buffers")
+        _hip = _CheckedLib(lib)
     return _hip
 
 

@@ -29,13 +29,15 @@ def stats_rows(m, cout):
     return 1
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None):
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None):
     out = F.conv2d(_nchw(x).float(), _nchw(w).float(), None if bias is None else bias.float()[: w.shape[0]],
                    stride=stride, padding=pad)
     out = _nhwc(out)
     stored = out.to(y.dtype)
     if stats is not None:
         sf = stored.float().reshape(-1, stored.shape[-1])
+        if stats_shift is not None:
+            sf = sf - stats_shift
         stats.zero_()
         stats[0, 0] = sf.sum(0)
         stats[0, 1] = (sf * sf).sum(0)
@@ -85,8 +87,10 @@ def bn_slab_rows(m):
     return 1
 
 
-def bn_stats(x, slab):
+def bn_stats(x, slab, shift=None):
     xf = x.float().reshape(-1, x.shape[-1])
+    if shift is not None:
+        xf = xf - shift
     slab.zero_()
     slab[0, 0] = xf.sum(0)
     slab[0, 1] = (xf * xf).sum(0)
@@ -94,10 +98,15 @@ def bn_stats(x, slab):
 
 
 def bn_finalize(slab, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift,
-                scratch=None):
+                scratch=None, stat_shift=None):
+    """The slab holds sum(x - c), sum((x - c)^2) about the per-channel shift c = stat_shift (0 if None); stat_shift is
+    refreshed to the new mean (shifted-data variance, csrc/hip/bn.hip: bn_finalize_kernel)."""
     s = slab.sum(0)
-    m = s[0] / count
-    var = (s[1] / count - m * m).clamp_min(0)
+    dm = s[0] / count
+    m = dm if stat_shift is None else stat_shift + dm
+    var = (s[1] / count - dm * dm).clamp_min(0)
+    if stat_shift is not None:
+        stat_shift.copy_(m)
     inv = torch.rsqrt(var + eps)
     mean.copy_(m)
     invstd.copy_(inv)

@@ -33,6 +33,10 @@ class DistributedModel:
         self.accum = torch.zeros(3, device=dev)            # epoch sums: loss, acc, iterations
         self._graph = None
         self._static_x = self._static_y = None
+        # DDP's `require_forward_param_sync` (torch/nn/parallel/distributed.py:1557-1558,1616-1617): True at wrap time
+        # and after every grad-enabled forward, dropped by a no-grad forward - i.e. the FIRST eval forward after a
+        # training step still broadcasts rank 0's BatchNorm statistics, later ones do not (X4 of SURVEY.md §2.6).
+        self._need_buffer_sync = True
 
     # ------------------------------------------------------------------ eager iteration
     def _forward_loss(self, x, labels, tape):
@@ -62,6 +66,7 @@ class DistributedModel:
             red.finish_and_step()
         from .. import ops
         ops.rng_advance(net.rng)
+        self._need_buffer_sync = True
 
     def timed_train_step(self, x, labels):
         """One iteration with HIP-event timing per phase (synchronises): {'forward': ms, 'backward': ms, 'optimizer': ms}."""
@@ -81,10 +86,15 @@ class DistributedModel:
             red.finish_and_step()
         from .. import ops
         ops.rng_advance(net.rng)
+        self._need_buffer_sync = True
         return t.result()
 
     def eval_step(self, x, labels):
         self.net.eval()
+        if self._need_buffer_sync:
+            if self.reducer is not None:
+                self.reducer.sync_buffers()
+            self._need_buffer_sync = False
         self._forward_loss(x, labels, None)
 
     # ------------------------------------------------------------------ hipGraph iteration (single-rank body)
@@ -100,6 +110,7 @@ class DistributedModel:
             state.append(opt.v)
         if st.p16 is not None:
             state.append(st.p16)
+        state.extend(st.aux_tensors)       # BatchNorm's statistics shift (previous batch mean) is carried state too
         saved = [t.clone() for t in state]
         host_step = opt._host_step
         s = torch.cuda.Stream()
@@ -122,6 +133,7 @@ class DistributedModel:
         self._static_x.copy_(x, non_blocking=True)
         self._static_y.copy_(labels, non_blocking=True)
         self._graph.replay()
+        self._need_buffer_sync = True
 
     # ------------------------------------------------------------------ metrics (host sync only here)
     def reset_epoch_metrics(self):

@@ -114,7 +114,7 @@ def _build(args, gpu, rank, modelName, cfg, with_optimizer):
             logging.info(f"fp32 convolution arithmetic: {cfg.FP32_MODE}")
     dataset = MNIST(args.dataPath, args.batchSize, get_model_input_size(modelName), worldSize=args.worldSize, rank=rank,
                     gpu=gpu, device=device, dtype=dtype, debug=bool(args.debug), seed=cfg.SEED,
-                    synthetic_ok=getattr(cfg, "SYNTHETIC_DATA", True))
+                    synthetic_ok=getattr(cfg, "SYNTHETIC_DATA", False))
     net, _ = get_model(modelName, dataset.nbClasses, cfg.FEATURE_EXTRACT, cfg.USE_PRETRAINED, device=device, dtype=dtype)
     net.seed_rng(cfg.SEED)
     loss_kind = cfg.LOSS if with_optimizer else "cross_entropy"

@@ -14,8 +14,8 @@ PY
 rc=0
 for m in resnet alexnet vgg squeezenet densenet inception; do
   mkdir -p $W/$m && cd $W/$m
-  if DPA_GPUS=0 DPA_MODEL_NAME=$m DPA_COMPUTE_DTYPE=$DT DPA_MASTER_PORT=29641 PYTHONPATH=$ROOT timeout -k 10 300 python $ROOT/main.py train -d $W/data -e 1 -b 32 --debug > train.log 2>&1 \
-     && DPA_GPUS=0 DPA_COMPUTE_DTYPE=$DT DPA_MASTER_PORT=29641 PYTHONPATH=$ROOT timeout -k 10 300 python $ROOT/main.py test -d $W/data -b 50 -f rsl/bestmodel-mnist-$m.pt.tar > test.log 2>&1; then
+  if DPA_SYNTHETIC_DATA=1 DPA_GPUS=0 DPA_MODEL_NAME=$m DPA_COMPUTE_DTYPE=$DT DPA_MASTER_PORT=29641 PYTHONPATH=$ROOT timeout -k 10 300 python $ROOT/main.py train -d $W/data -e 1 -b 32 --debug > train.log 2>&1 \
+     && DPA_SYNTHETIC_DATA=1 DPA_GPUS=0 DPA_COMPUTE_DTYPE=$DT DPA_MASTER_PORT=29641 PYTHONPATH=$ROOT timeout -k 10 300 python $ROOT/main.py test -d $W/data -b 50 -f rsl/bestmodel-mnist-$m.pt.tar > test.log 2>&1; then
     echo "$m $DT: $(grep -h 'Train  ' train.log | tail -1 | sed 's/ *| */ /g') | $(grep -h 'Acc:' test.log | tail -1)"
   else
     echo "$m $DT: FAILED"; tail -5 train.log test.log 2>/dev/null; rc=1

@@ -38,7 +38,7 @@ from distributedpytorch_amd.parallel.ddp import DistributedModel  # noqa: E402
 
 def make_dataset(path, batch, dtype, seed):
     torch.manual_seed(seed)       # random_split uses the global RNG (utils.py:188-194 before dataloader.py:129)
-    return mnist.MNIST(path, batch, 224, worldSize=1, rank=0, gpu=0, device=torch.device("cuda", 0), dtype=dtype, seed=seed)
+    return mnist.MNIST(path, batch, 224, worldSize=1, rank=0, gpu=0, device=torch.device("cuda", 0), dtype=dtype, seed=seed, synthetic_ok=True)
 
 
 def run_engine(path, dtype, epochs, batch, seed, init_sd=None):
@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--data", default="")
     a = ap.parse_args()
     path = a.data or tempfile.mkdtemp(prefix="dpa_mnist_")
-    if not mnist.have_mnist(path):
+    if not mnist.have_mnist(path) and not mnist.have_synthetic(path):
         mnist.generate_synthetic_mnist(path, n_train=a.n_train, n_test=a.n_test, seed=a.seed)
     res = {"config": vars(a), "data": "synthetic MNIST (data/mnist.py generator; real MNIST is not available offline)"}
     print("engine fp32", flush=True)

@@ -68,6 +68,53 @@ def test_ddp_gloo_two_ranks(tmp_path, sync_comm):
     assert r0["loss"][2] == 3
 
 
+def _eval_sync_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.parallel import comm
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    from tests.helpers import to_nhwc_padded
+    torch.set_num_threads(2)
+    comm.init_process_group(rank, world, torch.device("cpu"), timeout_s=120)
+    torch.manual_seed(3)
+    net, _ = get_model("resnet", 10, device="cpu", small_input=True)
+    dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3))
+    g = torch.Generator().manual_seed(50 + rank)                # DIFFERENT training data per rank -> different BN statistics
+    for _ in range(2):
+        dm.train_step(to_nhwc_padded(torch.randn(4, 3, 16, 16, generator=g), torch.float32, "cpu"),
+                      torch.randint(0, 10, (4,), generator=g))
+    b_before = net.store.b.clone()
+    ge = torch.Generator().manual_seed(99)                      # SAME evaluation batch on both ranks
+    xe = to_nhwc_padded(torch.randn(4, 3, 16, 16, generator=ge), torch.float32, "cpu")
+    ye = torch.randint(0, 10, (4,), generator=ge)
+    dm.reset_epoch_metrics()
+    dm.eval_step(xe, ye)
+    first = dm.epoch_metrics()
+    flag_after_first = dm._need_buffer_sync
+    dm.eval_step(xe, ye)
+    torch.save({"b_before": b_before, "b": net.store.b.clone(), "nbt": net.store.nbt.clone(), "loss": first[0],
+                "flag": flag_after_first}, os.path.join(out_dir, f"eval{rank}.pt"))
+    comm.destroy_process_group()
+
+
+def test_first_eval_forward_after_training_broadcasts_rank0_buffers(tmp_path):
+    """X4 of SURVEY.md §2.6 (torch DDP behind /root/reference/classif.py:159): after a training phase the ranks' BatchNorm
+    running statistics differ (each saw its own last batch); the first evaluation forward broadcasts rank 0's, so every
+    rank evaluates the same model and reports the same validation loss on the same inputs."""
+    mp.spawn(_eval_sync_worker, nprocs=2, args=(2, _free_port(), str(tmp_path)), join=True)
+    r0 = torch.load(tmp_path / "eval0.pt")
+    r1 = torch.load(tmp_path / "eval1.pt")
+    assert not torch.equal(r0["b_before"], r1["b_before"])      # the last training step left rank-local statistics
+    assert torch.equal(r0["b"], r0["b_before"])                 # rank 0's statistics win ...
+    assert torch.equal(r1["b"], r0["b"]) and torch.equal(r1["nbt"], r0["nbt"])
+    assert r0["loss"] == r1["loss"]                             # ... and rank 1's validation loss equals rank 0's
+    assert r0["flag"] is False and r1["flag"] is False          # later eval forwards do not broadcast again
+
+
 def _single_vs_ddp_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -117,7 +164,7 @@ def test_ddp_equals_single_process_full_batch(tmp_path):
 
 def _run_cli(tmp_path, args, env_extra, timeout=600):
     env = dict(os.environ, DPA_MODEL_NAME="basic", DPA_GPUS="0,1", DPA_MASTER_PORT=str(_free_port()), DPA_NUM_THREADS="4",
-               PYTHONPATH=ROOT, **env_extra)
+               DPA_SYNTHETIC_DATA="1", PYTHONPATH=ROOT, **env_extra)
     return subprocess.run([sys.executable, os.path.join(ROOT, "main.py")] + args, cwd=tmp_path, env=env, capture_output=True,
                           text=True, timeout=timeout)
 
@@ -172,7 +219,7 @@ def test_cli_two_nodes_two_launchers(tmp_path, tiny_data):
     order, rendezvous goes through the C++ store and gloo, and only global rank 0 writes the checkpoint."""
     port = str(_free_port())
     common = dict(os.environ, DPA_MODEL_NAME="basic", DPA_DDT_NODES="127.0.0.1:0;127.0.0.2:0", DPA_MASTER_ADDR="127.0.0.1",
-                  DPA_MASTER_PORT=port, DPA_NUM_THREADS="2", PYTHONPATH=ROOT)
+                  DPA_MASTER_PORT=port, DPA_NUM_THREADS="2", DPA_SYNTHETIC_DATA="1", PYTHONPATH=ROOT)
     procs = []
     for i, addr in enumerate(("127.0.0.1", "127.0.0.2")):
         wd = tmp_path / f"node{i}"

@@ -32,11 +32,10 @@ def _run(name, oracle, hw, n, dtype, small_input=False):
             assert rel < 5e-2, (k, rel)
     else:
         assert abs(loss - ref_loss) < 0.05 * max(1.0, abs(ref_loss))
-        # bf16 activations: compare gradient direction, not digits
-        for k in ("fc.weight", "layer4.1.conv2.weight", "layer1.0.conv1.weight", "conv1.weight"):
-            if k in ref_g:
-                cos = torch.nn.functional.cosine_similarity(g[k].flatten(), ref_g[k].flatten(), dim=0).item()
-                assert cos > 0.9, (k, cos)
+        # bf16 activations / MFMA operands, fp32 accumulation and master weights: every parameter's gradient within
+        # 10 % relative L2 of the fp64 oracle (a wrong-by-10 % gradient must not pass)
+        worst = max(((g[k] - v).norm().item() / max(v.norm().item(), 1e-12), k) for k, v in ref_g.items())
+        assert worst[0] < 0.1, worst
     logits_e, _, _ = framework_step(net, x, y, train=False)
     ref_e, _ = oracle_step(oracle, x.double(), y, train=False)
     ref_e = ref_e.float()

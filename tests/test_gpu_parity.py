@@ -1,0 +1,127 @@
+"""Direct comparisons against torch's own operators (not the builder's ref_ops): F.batch_norm including the running
+statistics, max_pool2d autograd per element, and the shifted-data variance on inputs with |mean| >> std."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(8, 14, 14, 64), (4, 7, 9, 24), (16, 5, 5, 2048)])
+def test_bn_train_step_matches_torch_batch_norm(shape):
+    """Three consecutive training steps of the HIP BatchNorm (bn_stats -> bn_finalize -> bn_apply and the backward pair)
+    against F.batch_norm on an fp64 copy: y, running_mean, running_var (unbiased, momentum 0.1), num_batches_tracked,
+    dgamma, dbeta, dx.  (torchvision BatchNorm2d behind /root/reference/utils.py:45.)"""
+    from distributedpytorch_amd.ops import hip_ops as H
+    n, h, w, c = shape
+    m = n * h * w
+    g = torch.Generator().manual_seed(4)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm_t, rv_t = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    cshift = torch.zeros(c, device="cuda")
+    gd, bd = gamma.cuda(), beta.cuda()
+    for step in range(3):
+        x = torch.randn(shape, generator=g) * 2.0 + 0.7 * step
+        dy = torch.randn(shape, generator=g)
+        # torch: NCHW fp64
+        xt = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+        gt, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        yt = F.batch_norm(xt, rm_t, rv_t, gt, bt, training=True, momentum=0.1, eps=1e-5)
+        yt.backward(dy.permute(0, 3, 1, 2).double())
+        # ours
+        xd, dyd = x.cuda(), dy.cuda()
+        slab = torch.zeros(H.bn_slab_rows(m), 2, c, device="cuda")
+        H.bn_stats(xd, slab, shift=cshift)
+        mean, invstd, scale, shift = (torch.zeros(c, device="cuda") for _ in range(4))
+        H.bn_finalize(slab, m, gd, bd, rm, rv, nbt, 0.1, 1e-5, mean, invstd, scale, shift, stat_shift=cshift)
+        y = torch.empty_like(xd)
+        H.bn_apply(xd, scale, shift, y, relu=False)
+        dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        sums, coef = torch.zeros(2, c, device="cuda"), torch.zeros(3, c, device="cuda")
+        H.bn_bwd_reduce(dyd, None, xd, mean, invstd, gd, dg, db, sums, coef)
+        dx = torch.empty_like(xd)
+        H.bn_bwd_dx(dyd, xd, coef, dx)
+        tol = dict(rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(y.cpu().double(), yt.detach().permute(0, 2, 3, 1), **tol)
+        torch.testing.assert_close(rm.cpu().double(), rm_t, **tol)
+        torch.testing.assert_close(rv.cpu().double(), rv_t, **tol)
+        assert int(nbt) == step + 1
+        sc = max(1.0, float(gt.grad.abs().max()))
+        torch.testing.assert_close(dg.cpu().double(), gt.grad, rtol=1e-4, atol=1e-4 * sc)
+        torch.testing.assert_close(db.cpu().double(), bt.grad, rtol=1e-4, atol=1e-4 * sc)
+        torch.testing.assert_close(dx.cpu().double(), xt.grad.permute(0, 2, 3, 1), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(cshift.cpu().double(), xt.detach().mean((0, 2, 3)), **tol)   # next step's shift
+
+
+def test_bn_variance_with_large_mean_small_std():
+    """E[x^2] - mean^2 in fp32 loses the variance when |mean| >> std (mean 100, std 0.1: 10000.01 - 10000).
+    With the statistics shifted by the previous step's batch mean the second step recovers it to fp32 accuracy; the
+    conv-epilogue statistics take the same shift."""
+    from distributedpytorch_amd.ops import hip_conv, hip_ops as H
+    c, shape = 64, (8, 28, 28, 64)
+    m = shape[0] * shape[1] * shape[2]
+    g = torch.Generator().manual_seed(9)
+    cshift = torch.zeros(c, device="cuda")
+    ones, zeros = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+    for step in range(2):
+        x = (100.0 + 0.1 * torch.randn(shape, generator=g)).cuda()
+        var64 = x.double().reshape(-1, c).var(0, unbiased=False)
+        slab = torch.zeros(H.bn_slab_rows(m), 2, c, device="cuda")
+        H.bn_stats(x, slab, shift=cshift)
+        mean, invstd, scale, shift = (torch.zeros(c, device="cuda") for _ in range(4))
+        H.bn_finalize(slab, m, ones, zeros, None, None, None, 0.1, 0.0, mean, invstd, scale, shift, stat_shift=cshift)
+        var = (1.0 / invstd.double() ** 2).cpu()
+        rel = ((var - var64.cpu()).abs() / var64.cpu()).max().item()
+        if step == 1:
+            assert rel < 1e-3, rel            # (fp32 data: x itself carries 8e-6 absolute rounding at 100)
+    assert rel < 1e-3
+    # the same through a 1x1 convolution's fused epilogue statistics (identity weights: z == x)
+    x = (100.0 + 0.1 * torch.randn(shape, generator=g)).cuda()
+    w = torch.eye(c, device="cuda").view(c, 1, 1, c).contiguous()
+    z = torch.empty_like(x)
+    rows = hip_conv.stats_rows(m, c)
+    slab = torch.zeros(rows, 2, c, device="cuda")
+    hip_conv.conv_fprop(x, w, z, (1, 1), (0, 0), stats=slab, stats_shift=cshift)
+    mean, invstd, scale, shift = (torch.zeros(c, device="cuda") for _ in range(4))
+    H.bn_finalize(slab, m, ones, zeros, None, None, None, 0.1, 0.0, mean, invstd, scale, shift, stat_shift=cshift)
+    var64 = z.double().reshape(-1, c).var(0, unbiased=False).cpu()
+    rel = (((1.0 / invstd.double() ** 2).cpu() - var64).abs() / var64).max().item()
+    assert rel < 1e-3, rel
+    torch.testing.assert_close(mean.cpu().double(), z.double().reshape(-1, c).mean(0).cpu(), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [((2, 56, 56, 64), 3, 2, 1, False), ((2, 27, 27, 64), 3, 2, 0, False),
+                                 ((2, 27, 27, 96), 3, 2, 0, True), ((2, 14, 14, 128), 2, 2, 0, False)])
+def test_maxpool_backward_per_element_vs_torch_autograd(cfg, dtype):
+    """Tie-free input (a random permutation of distinct values per channel plane), so the argmax tap is unique and the
+    gradient must land on exactly the element torch's max_pool2d autograd picks."""
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    shape, k, s, p, ceil = cfg
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(2)
+    if dtype == torch.bfloat16 and h * w > 256:
+        pytest.skip("bf16 holds at most 256 consecutive integers exactly: no tie-free plane of this size")
+    vals = torch.stack([torch.randperm(h * w, generator=g) for _ in range(n * c)]).float()
+    x = vals.view(n, c, h, w).permute(0, 2, 3, 1).contiguous()
+    ho, wo = R.pool_out_size(h, k, s, p, ceil), R.pool_out_size(w, k, s, p, ceil)
+    dy = torch.randn(n, ho, wo, c, generator=g)
+    xt = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yt = F.max_pool2d(xt, k, s, p, ceil_mode=ceil)
+    yt.backward(dy.permute(0, 3, 1, 2))
+    xd = x.to("cuda", dtype)
+    y = torch.empty(n, ho, wo, c, device="cuda", dtype=dtype)
+    idx = torch.empty(n, ho, wo, c, device="cuda", dtype=torch.uint8)
+    H.maxpool_fwd(xd, y, idx, (k, k), (s, s), (p, p))
+    dx = torch.empty_like(xd)
+    H.maxpool_bwd(dy.to("cuda", dtype), idx, dx, (k, k), (s, s), (p, p))
+    torch.testing.assert_close(y.float().cpu(), yt.detach().permute(0, 2, 3, 1), rtol=0, atol=0)
+    ref_dx = xt.grad.permute(0, 2, 3, 1)
+    if dtype == torch.float32:
+        torch.testing.assert_close(dx.cpu(), ref_dx, rtol=1e-6, atol=1e-6)
+    else:
+        # overlapping windows (k > s) sum several bf16 gradients: same support, values to bf16 rounding
+        assert torch.equal(dx.float().cpu() != 0, ref_dx != 0)
+        torch.testing.assert_close(dx.float().cpu(), ref_dx, rtol=2e-2, atol=2e-2)

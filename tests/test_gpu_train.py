@@ -78,7 +78,7 @@ def test_feature_extract_only_updates_head():
 
 def test_cli_mnist_train_and_test_on_gpu(tmp_path):
     """python main.py train -d ... -e 1 --debug on one MI355X, then main.py test; checkpoint loads into torch."""
-    env = dict(os.environ, DPA_GPUS="0", DPA_MASTER_PORT="29533", PYTHONPATH=ROOT, DPA_MODEL_NAME="resnet")
+    env = dict(os.environ, DPA_GPUS="0", DPA_MASTER_PORT="29533", PYTHONPATH=ROOT, DPA_MODEL_NAME="resnet", DPA_SYNTHETIC_DATA="1")
     data = str(tmp_path / "data")
     sys.path.insert(0, ROOT)
     from distributedpytorch_amd.data import mnist

@@ -121,3 +121,147 @@ def test_x6_backward_error_with_wide_dynamic_range():
         set_fp32_mode(prev)
     assert errs["exact"] < 1e-5, errs
     assert errs["x6"] < max(2.0 * errs["exact"], 3e-7), errs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Per-element backward-error bounds for EVERY x6 instantiation: fprop / dgrad / wgrad on the
+# LDS-DMA staged kernels, the register-staged variant (short reductions), the split-K variant (Linear-shaped problems)
+# and the general (non-uniform-tap) address path.  Operands span 2^-20..2^20 with full 24-bit significands; the error
+# of each output element is measured against sum_k |a_k||b_k| - the scale a dropped 2^-23 term of any single product
+# is relative to.
+def _wide(shape, g, lo, hi):
+    mag = torch.exp2(torch.randint(lo, hi, shape, device="cuda", generator=g).float())
+    return torch.randn(shape, device="cuda", generator=g) * mag
+
+
+# name, (N, H, W, C, K, k, stride, pad), which kernel variant the shape is routed to
+X6_VARIANTS = [
+    ("glds_3x3", (8, 14, 14, 256, 128, 3, 1, 1)),          # LDS-DMA staged, uniform taps
+    ("glds_stride2", (8, 28, 28, 128, 128, 3, 2, 1)),      # dgrad parity classes
+    ("regstaged_1x1_shortK", (4, 56, 56, 64, 256, 1, 1, 0)),   # nkt = 2 < 8: register-staged x6 instantiation
+    ("general_path_odd", (4, 17, 13, 40, 72, 5, 1, 2)),    # C % 32 != 0: general address path
+    ("tall_narrow_256x64", (64, 56, 56, 64, 64, 3, 1, 1)),  # dC <= 64 and >= 256 M-tiles of 256: the 256 x 64 tile
+]
+
+
+@pytest.mark.parametrize("name,shape", X6_VARIANTS)
+def test_x6_per_element_bound_fprop_dgrad_wgrad(name, shape):
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(321)
+    x = _wide((N, H, W, C), g, -20, 20)
+    w = _wide((K, k, k, C), g, -10, 10)
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    dy = _wide((N, Ho, Wo, K), g, -20, 20)
+    xd, wd, dyd = x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double()
+    refs = {
+        "fprop": (F.conv2d(xd, wd, stride=s, padding=pd), F.conv2d(xd.abs(), wd.abs(), stride=s, padding=pd)),
+        "dgrad": (torch.nn.grad.conv2d_input((N, C, H, W), wd, dyd, stride=s, padding=pd),
+                  torch.nn.grad.conv2d_input((N, C, H, W), wd.abs(), dyd.abs(), stride=s, padding=pd)),
+        "wgrad": (torch.nn.grad.conv2d_weight(xd, (K, C, k, k), dyd, stride=s, padding=pd),
+                  torch.nn.grad.conv2d_weight(xd.abs(), (K, C, k, k), dyd.abs(), stride=s, padding=pd)),
+    }
+    errs = {}
+    prev = set_fp32_mode("exact")
+    try:
+        for mode in ("exact", "x6"):
+            set_fp32_mode(mode)
+            y = torch.empty(N, Ho, Wo, K, device="cuda")
+            hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd))
+            dx = torch.empty(N, H, W, C, device="cuda")
+            hip_conv.conv_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), dx, (s, s), (pd, pd))
+            dw = torch.empty(K, k, k, C, device="cuda")
+            ws = torch.empty(hip_conv.wgrad_workspace_numel(K, k * k * C), device="cuda")
+            hip_conv.conv_wgrad(dy, x, dw, (k, k), (s, s), (pd, pd), workspace=ws)
+            for what, out in (("fprop", y), ("dgrad", dx), ("wgrad", dw)):
+                ref, scale = refs[what]
+                assert torch.isfinite(out).all(), (mode, what)
+                e = ((out.permute(0, 3, 1, 2).double() - ref).abs() / scale.clamp_min(1e-300)).max().item()
+                errs[(mode, what)] = e
+    finally:
+        set_fp32_mode(prev)
+    for what in ("fprop", "dgrad", "wgrad"):
+        e, v = errs[("exact", what)], errs[("x6", what)]
+        assert e < 2e-5, (name, what, errs)
+        # fp32 accumulation of the same length in both modes; x6 adds <= 3 dropped terms of 2^-24 per product
+        assert v < max(2.0 * e, 4e-7), (name, what, errs)
+
+
+def test_x6_per_element_bound_splitk_linear():
+    """Linear-shaped GEMM (64 x 9216 x 4096: few output tiles, long reduction) takes the split-K instantiation; its x6
+    variant must meet the same per-element bound, forward and data-gradient."""
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    M, Kin, Kout = 64, 9216, 4096
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = _wide((M, 1, 1, Kin), g, -12, 12)
+    w = _wide((Kout, 1, 1, Kin), g, -8, 8)
+    dy = _wide((M, 1, 1, Kout), g, -12, 12)
+    x2, w2, dy2 = x.view(M, Kin).double(), w.view(Kout, Kin).double(), dy.view(M, Kout).double()
+    ref_y, sc_y = x2 @ w2.t(), x2.abs() @ w2.abs().t()
+    ref_dx, sc_dx = dy2 @ w2, dy2.abs() @ w2.abs()
+    errs = {}
+    prev = set_fp32_mode("exact")
+    try:
+        for mode in ("exact", "x6"):
+            set_fp32_mode(mode)
+            y = torch.empty(M, 1, 1, Kout, device="cuda")
+            hip_conv.conv_fprop(x, w, y, (1, 1), (0, 0))
+            dx = torch.empty(M, 1, 1, Kin, device="cuda")
+            hip_conv.conv_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), dx, (1, 1), (0, 0))
+            errs[(mode, "fprop")] = ((y.view(M, Kout).double() - ref_y).abs() / sc_y).max().item()
+            errs[(mode, "dgrad")] = ((dx.view(M, Kin).double() - ref_dx).abs() / sc_dx).max().item()
+    finally:
+        set_fp32_mode(prev)
+    for what in ("fprop", "dgrad"):
+        e, v = errs[("exact", what)], errs[("x6", what)]
+        assert e < 2e-5 and v < max(2.0 * e, 4e-7), errs
+
+
+def test_x6_subnormal_inf_nan_propagation():
+    """Special values through the 3-way bf16 split (bf16 shares fp32's exponent range, so the split itself never
+    overflows or underflows a normal number):
+      * subnormal and tiny-normal inputs: finite outputs, absolute error within the exact path's bound (no NaN from
+        0 * x or from remainders of subnormals);
+      * +-inf or NaN in ONE input element: every output that depends on it is non-finite in both modes (x6 turns an
+        inf into NaN because inf - inf appears in the remainder: non-finite stays non-finite, never a finite number),
+        every other output equals the clean run bit for bit."""
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    N, H, W, C, K, k = 4, 14, 14, 256, 128, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.randn(K, k, k, C, device="cuda", generator=g)
+    x_tiny = torch.randn(N, H, W, C, device="cuda", generator=g) * 1e-38       # mixes subnormals and tiny normals
+    x_tiny[0, :, :, ::2] *= 1e-4                                                # deep subnormals (1e-42)
+    x_clean = torch.randn(N, H, W, C, device="cuda", generator=g)
+    prev = set_fp32_mode("exact")
+    try:
+        outs = {}
+        for mode in ("exact", "x6"):
+            set_fp32_mode(mode)
+            y = torch.empty(N, H, W, K, device="cuda")
+            hip_conv.conv_fprop(x_tiny, w, y, (1, 1), (1, 1))
+            assert torch.isfinite(y).all(), mode
+            outs[mode] = y.double()
+        ref = F.conv2d(x_tiny.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+        scale = F.conv2d(x_tiny.permute(0, 3, 1, 2).double().abs(), w.permute(0, 3, 1, 2).double().abs(), padding=1).permute(0, 2, 3, 1)
+        # gradual underflow: results near 1e-36 keep their relative accuracy, contributions below 2^-149 may flush
+        for mode in ("exact", "x6"):
+            err = ((outs[mode] - ref).abs() - 1e-43 * k * k * C).clamp_min(0) / scale
+            assert err.max().item() < 1e-5, (mode, err.max().item())
+        for bad in (float("inf"), float("-inf"), float("nan")):
+            for mode in ("exact", "x6"):
+                set_fp32_mode(mode)
+                y0 = torch.empty(N, H, W, K, device="cuda")
+                hip_conv.conv_fprop(x_clean, w, y0, (1, 1), (1, 1))
+                xb = x_clean.clone()
+                xb[1, 5, 6, 17] = bad
+                y1 = torch.empty(N, H, W, K, device="cuda")
+                hip_conv.conv_fprop(xb, w, y1, (1, 1), (1, 1))
+                touched = torch.zeros(N, H, W, dtype=torch.bool, device="cuda")
+                touched[1, 4:7, 5:8] = True                                      # 3x3 window around (5, 6)
+                assert not torch.isfinite(y1[touched]).any(), (mode, bad)
+                assert torch.equal(y1[~touched], y0[~touched]), (mode, bad)
+    finally:
+        set_fp32_mode(prev)

@@ -106,7 +106,7 @@ def test_mnist_split_sizes_stats_and_determinism(small_mnist):
     sets = []
     for rank in (0, 1):
         setRandomSeed(1234)
-        ds = MNIST(small_mnist, 32, 28, worldSize=2, rank=rank, gpu=0, device=torch.device("cpu"))
+        ds = MNIST(small_mnist, 32, 28, worldSize=2, rank=rank, gpu=0, device=torch.device("cpu"), synthetic_ok=True)
         sets.append(ds)
     a, b = sets
     assert len(a.data["train"]) == 540 and len(a.data["valid"]) == 60 and len(a.data["test"]) == 100
@@ -126,9 +126,22 @@ def test_mnist_split_sizes_stats_and_determinism(small_mnist):
     assert w.shape == (10,) and torch.all(w > 0)
 
 
+def test_missing_mnist_fails_like_the_reference_unless_opted_in(tmp_path):
+    """A mistyped -d must not silently train on generated data (the reference: torchvision MNIST(download=False) raises);
+    opted in, the stand-in lives under MNIST-synthetic/raw - never under the real dataset's MNIST/raw."""
+    from distributedpytorch_amd.data import mnist
+    with pytest.raises(FileNotFoundError):
+        mnist.MNIST(str(tmp_path), 32, 28, worldSize=1, rank=0, gpu=-1, device=torch.device("cpu"))
+    assert not os.path.exists(mnist.raw_dir(str(tmp_path)))
+    mnist.generate_synthetic_mnist(str(tmp_path), n_train=200, n_test=50, seed=1)
+    assert mnist.have_synthetic(str(tmp_path)) and not mnist.have_mnist(str(tmp_path))
+    ds = mnist.MNIST(str(tmp_path), 32, 28, worldSize=1, rank=0, gpu=-1, device=torch.device("cpu"), synthetic_ok=True)
+    assert len(ds.data["train"]) == 180
+
+
 def test_mnist_debug_subset(small_mnist):
     from distributedpytorch_amd.data.mnist import MNIST
-    ds = MNIST(small_mnist, 32, 28, worldSize=1, rank=0, gpu=0, device=torch.device("cpu"), debug=True)
+    ds = MNIST(small_mnist, 32, 28, worldSize=1, rank=0, gpu=0, device=torch.device("cpu"), debug=True, synthetic_ok=True)
     assert len(ds.data["train"]) == 200 and len(ds.data["valid"]) == 60
 
 
@@ -203,6 +216,38 @@ def test_arena_optimizer_matches_torch_and_state_dict(kind):
     opt2.load_state_dict(ref_sd)
     torch.testing.assert_close(opt2.m, opt.m, rtol=1e-4, atol=1e-6)
     assert float(opt2.hyper[5]) == float(opt.hyper[5]) or kind == "SGD"
+
+
+def test_feature_extract_optimizer_state_dict_loads_into_reference_adam():
+    """FEATURE_EXTRACT=True: the reference still builds Adam over model.parameters() - all 62 of them, frozen ones
+    included (/root/reference/classif.py:124, utils.py:107-110) - so `params` must index every parameter and only the
+    trainable head carries state.  torch.optim.Adam(oracle.parameters()).load_state_dict must accept ours."""
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from tests import torch_ref_models as ref
+    from tests.helpers import framework_step
+    torch.manual_seed(0)
+    net, _ = get_model("resnet", 10, feature_extract=True, device="cpu", small_input=True)
+    opt = ArenaOptimizer(net.store, "adam", lr=1e-3)
+    framework_step(net, torch.randn(4, 3, 16, 16), torch.randint(0, 10, (4,)))
+    opt.step()
+    sd = opt.state_dict()
+    n_all = len(net.store.params)
+    assert n_all == 62 and sd["param_groups"][0]["params"] == list(range(n_all))
+    assert sorted(sd["state"]) == [n_all - 2, n_all - 1]               # fc.weight, fc.bias: the only trainable ones
+    oracle = ref.resnet18(10, small_input=True)
+    for name, p in oracle.named_parameters():                          # utils.setParameterRequiresGrad + new head
+        p.requires_grad = name.startswith("fc.")
+    topt = torch.optim.Adam(oracle.parameters(), lr=1e-3)              # the reference's construction
+    topt.load_state_dict(sd)
+    got = topt.state_dict()["state"]
+    assert sorted(got) == [n_all - 2, n_all - 1]
+    torch.testing.assert_close(got[n_all - 2]["exp_avg"], sd["state"][n_all - 2]["exp_avg"])
+    # round trip through our loader
+    opt2 = ArenaOptimizer(net.store, "adam", lr=1e-3)
+    opt2.load_state_dict(topt.state_dict())
+    torch.testing.assert_close(opt2.m, opt.m)
+    torch.testing.assert_close(opt2.v, opt.v)
 
 
 # ------------------------------------------------------------------------------------------------ losses
