@@ -68,12 +68,12 @@ USE_PRETRAINED = _env("USE_PRETRAINED", False, bool)
 NUM_THREADS = _env("NUM_THREADS", 32, int)
 
 # ----------------------------------------------------------------------------- MI355X-native additions
-COMPUTE_DTYPE = _env("COMPUTE_DTYPE", 'fp32')     # fp32 (exact f32 MFMA; the reference's precision) | bf16 (bf16 MFMA, fp32 accumulate + fp32 master weights; ~3x faster)
-FP32_MODE = _env("FP32_MODE", 'exact')            # exact (v_mfma_f32_16x16x4_f32) | x6 (each fp32 product as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate: error vs fp64 not above the exact path's, conv kernels ~1.35x faster)
+COMPUTE_DTYPE = _env("COMPUTE_DTYPE", 'fp32')     # fp32 (fp32 in / out / accumulate: the reference's precision; arithmetic per FP32_MODE) | bf16 (bf16 MFMA, fp32 accumulate + fp32 master weights; ~3x faster)
+FP32_MODE = _env("FP32_MODE", 'x6')               # x6 (default: each fp32 product as 6 bf16 MFMA products of EXACT 3-way bf16 operand splits, fp32 accumulate; per-element error vs fp64 not above the exact path's on every kernel variant, tests/test_gpu_x6.py) | exact (v_mfma_f32_16x16x4_f32: bit-for-bit an fp32 fma chain, ~1.3x slower convolutions)
 FIRST_BUCKET_MB = _env("FIRST_BUCKET_MB", 1.0, float)    # DDP first (last-layer) bucket
-BUCKET_CAP_MB = _env("BUCKET_CAP_MB", 25.0, float)       # DDP bucket cap, sized for 7 xGMI links per GPU
+BUCKET_CAP_MB = _env("BUCKET_CAP_MB", 25.0, float)       # DDP bucket cap: torch DDP's default, NOT yet swept on an 8-GPU node (scripts/allreduce_bench.py --sweep does it; SURVEY.md §5.8 expects 16-32 MiB to keep each of the 7 xGMI links bandwidth-bound)
 BROADCAST_BUFFERS = _env("BROADCAST_BUFFERS", True, bool)  # DDP semantics: rank 0's BatchNorm statistics win every step
-COMM_BACKEND = _env("COMM_BACKEND", 'torch')       # torch (torch.distributed: RCCL process group / gloo) | rccl_native (C++ communicator + reducer core, csrc/comm)
+COMM_BACKEND = _env("COMM_BACKEND", 'native')      # native (default: C++ store rendezvous + ONE native communicator per rank - RCCL over xGMI on GPUs, TCP mesh on CPUs; csrc/comm) | torch (fallback: torch.distributed RCCL process group / gloo)
 USE_HIPGRAPH = _env("USE_HIPGRAPH", True, bool)   # replay the training iteration from a hipGraph when world_size == 1
 SYNC_COMM = _env("SYNC_COMM", False, bool)        # debug: synchronous collectives (race-detection aid)
 GLOBAL_METRICS = _env("GLOBAL_METRICS", False, bool)  # all-reduce (loss, acc) over ranks; False = reference behaviour
@@ -85,4 +85,5 @@ SYNTHETIC_DATA = _env("SYNTHETIC_DATA", False, bool)  # opt-in: when the real ID
 # RCCL/NCCL transport knobs for multi-node runs, exported by the launcher when set (the reference keeps a commented
 # NCCL_IB_DISABLE line, main.py:131): e.g. DPA_NCCL_ENV="NCCL_IB_DISABLE=1,NCCL_SOCKET_IFNAME=eth0"
 NCCL_ENV = _env("NCCL_ENV", '')
+STEP_METRICS = _env("STEP_METRICS", True, bool)   # global rank 0 writes <RSL_PATH>/steps.jsonl: step, loss, acc, images/s, data ms, comm ms, phase ms (HIP events, no host sync in the loop)
 FAULT_INJECT = _env("FAULT_INJECT", '')          # test hook "rank:step": that rank exits(17) at that global step

@@ -61,9 +61,10 @@ def build(force=False, jobs=None, verbose=True):
     host_src = _sources("host", (".cpp",))
     host_hdr = _sources("host", (".h",))
     comm_src = _sources("comm", (".cpp",))
+    comm_hdr = _sources("comm", (".h",))
     tasks = []
     objs = {"hip": [], "host": [], "comm": []}
-    for kind, srcs, hdrs in (("hip", hip_src, hip_hdr), ("host", host_src, host_hdr), ("comm", comm_src, [])):
+    for kind, srcs, hdrs in (("hip", hip_src, hip_hdr), ("host", host_src, host_hdr), ("comm", comm_src, comm_hdr)):
         for src in srcs:
             base = os.path.splitext(os.path.basename(src))[0]
             obj = os.path.join(OBJDIR, f"{kind}_{base}.o")
@@ -104,7 +105,7 @@ def build(force=False, jobs=None, verbose=True):
     comm_so = os.path.join(LIBDIR, "libdpamd_comm.so")
     if objs["comm"] and (relink or not os.path.exists(comm_so)):
         # like the kernel library: no rpath, so librccl.so.1 / libamdhip64.so.7 bind to the copies torch has loaded
-        cmd = ["g++", "-shared", "-fPIC", "-o", comm_so] + objs["comm"] + [f"-L{ROCM}/lib", "-lrccl", "-lamdhip64"]
+        cmd = ["g++", "-shared", "-fPIC", "-pthread", "-o", comm_so] + objs["comm"] + [f"-L{ROCM}/lib", "-lrccl", "-lamdhip64"]
         subprocess.run(cmd, check=True)
         if verbose:
             print(f"[build] linked {os.path.relpath(comm_so, PKG)}", flush=True)

@@ -86,7 +86,7 @@ template <> struct MfmaT<float> {
 // fp64 reference the result is slightly MORE accurate than the exact-fp32 16x16x4 MFMA chain (fewer accumulator
 // roundings: 32 products per instruction instead of 4) - scripts/x6_accuracy.py, profiles/README.md.
 // The bf16 pipe does 16x the MACs per cycle of the fp32 one, so 6 products still cost 2.7x fewer matrix cycles.
-extern "C" int dpa_get_fp32_mode();      // 0 = exact fp32 MFMA (default), 1 = x6; DPA_FP32_MODE / dpa_set_fp32_mode
+extern "C" int dpa_get_fp32_mode();      // 0 = exact fp32 MFMA, 1 = x6 (default); DPA_FP32_MODE / dpa_set_fp32_mode
 __device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) {
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

@@ -515,11 +515,11 @@ DPA_API int dpa_init_workspaces() {
 }
 
 // fp32 arithmetic mode of the convolution kernels (fprop / dgrad here, wgrad in conv_wgrad.hip): 0 = exact fp32 MFMA,
-// 1 = x6 (fp32 through 6 bf16 MFMAs per product, see X6 above).  Initial value from DPA_FP32_MODE=exact|x6; the
+// 1 = x6 (fp32 through 6 bf16 MFMAs per product, see X6 above; the default).  Initial value from DPA_FP32_MODE=exact|x6; the
 // Python layer switches it with dpa_set_fp32_mode (between launches; a captured hipGraph keeps the mode it was captured in).
 static int g_fp32_mode = -1;
 DPA_API int dpa_get_fp32_mode() {
-  if (g_fp32_mode < 0) { const char* e = getenv("DPA_FP32_MODE"); g_fp32_mode = (e && e[0] == 'x') ? 1 : 0; }
+  if (g_fp32_mode < 0) { const char* e = getenv("DPA_FP32_MODE"); g_fp32_mode = (e && e[0] == 'e') ? 0 : 1; }
   return g_fp32_mode;
 }
 DPA_API void dpa_set_fp32_mode(int mode) { g_fp32_mode = mode ? 1 : 0; }

@@ -125,7 +125,7 @@ FP32_MODES = ("exact", "x6")
 
 
 def set_fp32_mode(mode: str) -> str:
-    """Arithmetic of the fp32 convolution kernels: 'exact' = v_mfma_f32_16x16x4_f32 (default), 'x6' = every fp32
+    """Arithmetic of the fp32 convolution kernels: 'exact' = v_mfma_f32_16x16x4_f32, 'x6' (default) = every fp32
     product as six bf16 x bf16 products of exact 3-way bf16 splits on the bf16 matrix pipe, fp32 accumulation
     (csrc/hip/conv_common.h).  Returns the previous mode.  Takes effect for launches issued afterwards."""
     if mode not in FP32_MODES:

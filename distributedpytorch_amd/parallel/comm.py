@@ -53,13 +53,99 @@ def destroy_process_group():
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The native path (default): ONE communicator per rank (parallel/native_comm.py), rendezvous and control plane on the
+# C++ TCP store - no torch.distributed process group.  COMM_BACKEND='torch' keeps the process-group path as fallback.
+_NATIVE = None
+_STORE = None
+STORE_PORT_OFFSET = 2          # the store listens on MASTER_PORT + 2 (MASTER_PORT itself belongs to torchrun's agent
+                               # when bench.py runs under torch.distributed.run; + 1 is the torch path's arrival check)
+
+
+def init_native(rank, world_size, device, master_addr=None, master_port=None, timeout_s=600.0, rendezvous_timeout_s=300.0,
+                transport=None, create_for_single_rank=False):
+    """Bring up the native communicator.  Returns it (None at world size 1 unless `create_for_single_rank`)."""
+    global _NATIVE, _STORE
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver stack
+    addr = str(master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    port = int(master_port or os.environ.get("MASTER_PORT", "6779")) + STORE_PORT_OFFSET
+    if world_size == 1 and not create_for_single_rank:
+        return None
+    from .native_comm import NativeComm
+    store = None
+    if world_size > 1:
+        from .store import TCPStore
+        store = TCPStore(addr, port, is_master=(rank == 0), timeout_s=rendezvous_timeout_s)
+        # every rank announces itself; on timeout the error NAMES the ranks that never arrived (the reference blocks
+        # forever in init_process_group, README.md:47-49)
+        store.announce_and_wait(rank, world_size, tag="join")
+        store.timeout_s = timeout_s
+    nc = NativeComm(store, rank, world_size, device, transport=transport, timeout_s=timeout_s, master_addr=addr)
+    _NATIVE, _STORE = nc, store
+    logging.debug(f"native communicator up: {nc.name} rank={rank}/{world_size}")
+    return nc
+
+
+def native():
+    return _NATIVE
+
+
+def shutdown(clean=True):
+    """Tear down whichever backend is up (Q17: the reference never calls destroy_process_group).  clean=False (an
+    exception is propagating): no farewell barrier - the other ranks may be stuck in a collective this rank left."""
+    global _NATIVE, _STORE
+    if _NATIVE is not None:
+        try:
+            if _NATIVE.async_error() != 0 or not clean:
+                _NATIVE.abort()
+            elif _STORE is not None:
+                _NATIVE.barrier("shutdown")        # nobody closes the store while others still use it
+        except Exception:       # noqa: BLE001 - shutdown path
+            pass
+        try:
+            _NATIVE.destroy()
+        except Exception:       # noqa: BLE001
+            pass
+        _NATIVE = None
+    if _STORE is not None:
+        try:
+            _STORE.close()
+        except Exception:       # noqa: BLE001
+            pass
+        _STORE = None
+    destroy_process_group()
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return world_size() > 1
 
 
 def world_size():
+    if _NATIVE is not None:
+        return _NATIVE.world
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
 def get_rank():
+    if _NATIVE is not None:
+        return _NATIVE.rank
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def all_reduce_scalars(values, op="sum", device=None):
+    """Reduce a few Python floats over all ranks (metrics, timing, checksums) on whichever backend is up."""
+    if _NATIVE is not None:
+        return _NATIVE.all_reduce_scalars(values, op)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                         device=device if device is not None and dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+        return t.tolist()
+    return [float(v) for v in values]
+
+
+def barrier():
+    if _NATIVE is not None:
+        _NATIVE.barrier()
+    elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

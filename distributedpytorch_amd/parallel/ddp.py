@@ -4,7 +4,7 @@ No host synchronisation happens inside: loss/accuracy accumulate on the device (
 
 `graph=True` captures the whole iteration (forward, backward, optimizer) into a hipGraph after a warm-up, which
 removes the per-kernel launch cost that dominates small-batch MNIST steps.  Collectives are
-not captured: graphs are used for world_size == 1 or for the forward/backward body only when requested.
+captured too when they go through the native RCCL communicator (`can_capture`).
 """
 from __future__ import annotations
 
@@ -33,6 +33,7 @@ class DistributedModel:
         self.accum = torch.zeros(3, device=dev)            # epoch sums: loss, acc, iterations
         self._graph = None
         self._static_x = self._static_y = None
+        self.steplog = None            # utils/steplog.StepLog, set by the trainer on global rank 0
         # DDP's `require_forward_param_sync` (torch/nn/parallel/distributed.py:1557-1558,1616-1617): True at wrap time
         # and after every grad-enabled forward, dropped by a no-grad forward - i.e. the FIRST eval forward after a
         # training step still broadcasts rank 0's BatchNorm statistics, later ones do not (X4 of SURVEY.md §2.6).
@@ -49,23 +50,29 @@ class DistributedModel:
             self.criterion(ctx, out, labels, self.net.num_classes, self.metrics, accum=self.accum)
         return ctx
 
-    def train_step(self, x, labels):
-        """x: NHWC compute-dtype batch on the device; labels: int64 on the device."""
+    def train_step(self, x, labels, mark=None):
+        """x: NHWC compute-dtype batch on the device; labels: int64 on the device.  mark(name): optional callback at
+        the end of each phase (utils/steplog.py records a HIP event there; never a host sync)."""
         net, red = self.net, self.reducer
+        mark = mark or (lambda name: None)
         net.train()
         with rng("sync_buffers"):
             red.sync_buffers()
+        mark("sync")
         tape = Tape()
         tape.param_ready_hook = red.param_ready
         red.begin_backward()
         with rng("forward+loss"):
             self._forward_loss(x, labels, tape)
+        mark("fwd")
         with rng("backward+allreduce"):
             tape.backward()
+        mark("bwd")
         with rng("wait+optimizer"):
             red.finish_and_step()
         from .. import ops
         ops.rng_advance(net.rng)
+        mark("wait_opt")
         self._need_buffer_sync = True
 
     def timed_train_step(self, x, labels):
@@ -99,8 +106,13 @@ class DistributedModel:
 
     # ------------------------------------------------------------------ hipGraph iteration (single-rank body)
     def capture_train_step(self, x, labels, warmup=3):
-        """Capture forward+backward+optimizer into a hipGraph (world_size == 1).  Returns False if unsupported."""
-        if self.device.type != "cuda" or self.reducer.world != 1:
+        """Capture the whole iteration into a hipGraph.  Returns False if unsupported.
+        Without collectives (world size 1) that is forward + backward + optimizer.  With collectives the native RCCL
+        communicator's work is captured too: the ready/done event fencing forks the capture onto the comm stream,
+        ncclAllReduce / ncclBroadcast are recorded there (RCCL supports stream capture) and the per-bucket waits join it
+        back before the optimizer kernels.  The torch process-group path and the staged TCP transport (host-side
+        waits) cannot be captured."""
+        if not self.can_capture():
             return False
         self._static_x, self._static_y = x.clone(), labels.clone()
         # warm-up iterations must not perturb training: snapshot every piece of mutable state and restore it
@@ -128,6 +140,14 @@ class DistributedModel:
             t.copy_(sv)
         opt._host_step = host_step
         return True
+
+    def can_capture(self):
+        if self.device.type != "cuda" or self.reducer is None:
+            return False
+        if not self.reducer.active:
+            return True
+        nc = self.reducer.native
+        return nc is not None and nc.transport == "rccl" and not self.reducer.sync_mode
 
     def replay_train_step(self, x, labels):
         self._static_x.copy_(x, non_blocking=True)

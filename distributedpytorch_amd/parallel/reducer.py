@@ -60,7 +60,7 @@ class GradReducer:
                  broadcast_buffers=True, sync_mode=False, process_group=None, native_comm=None):
         self.store, self.opt = store, optimizer
         self.pg = process_group
-        self.native = native_comm            # NativeRcclComm: own comm stream + hipEvent fencing (csrc/comm)
+        self.native = native_comm            # NativeComm: one communicator per rank (csrc/comm), no process group
         if native_comm is not None:
             self.world, self.rank = native_comm.world, native_comm.rank
         else:
@@ -71,28 +71,25 @@ class GradReducer:
         for bi, bk in enumerate(self.buckets):
             for s in bk["params"]:
                 self.bucket_of[s.index] = bi
-        self._core_lib, self._core = self._make_core()
         self.broadcast_buffers = broadcast_buffers
         self.sync_mode = sync_mode            # debug: run every collective synchronously (race detection aid)
         # DPA_FORCE_COLLECTIVES=1: issue every collective even at world_size 1 (single-GPU rehearsal of the RCCL
         # stream/event path; a 1-rank all-reduce is the identity)
-        self.force = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+        self.force = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1" and (native_comm is not None or dist.is_initialized())
+        self.active = self.world > 1 or self.force          # are collectives issued at all?
+        self._core_lib, self._core = self._make_core()
         self._pending = None
         self._works = None
         self.comm_bytes = sum((b["hi"] - b["lo"]) * 4 for b in self.buckets)
         optimizer.set_grad_scale(1.0 / self.world)
-        if self.native is not None:
-            for t in (self.store.p, self.store.b, self.store.nbt):
-                self.native.broadcast(t, 0)
-            self.store.refresh_compute_copy()
-        elif self.world > 1 or self.force:
+        if self.active:
             self._verify_and_broadcast()
 
     def _make_core(self):
         """The C++ reducer core (csrc/comm/reducer.cpp): pending counters, ready detection, launch of the bucket's
         all-reduce on the native communicator's stream.  With the torch.distributed backend (RCCL process group or
         gloo) the core does the bookkeeping and this class issues the collective for the bucket it returns."""
-        from .rccl_native import comm_lib
+        from .native_comm import comm_lib
         lib = comm_lib()
         n = len(self.store.params)
         bo = (ctypes.c_int * n)(*[self.bucket_of.get(s.index, -1) for s in self.store.params])
@@ -100,7 +97,7 @@ class GradReducer:
         nb = len(self.buckets)
         lo = (ctypes.c_longlong * max(nb, 1))(*[b["lo"] for b in self.buckets])
         hi = (ctypes.c_longlong * max(nb, 1))(*[b["hi"] for b in self.buckets])
-        comm_h = ctypes.c_void_p(self.native.h) if self.native is not None else ctypes.c_void_p(0)
+        comm_h = ctypes.c_void_p(self.native.h) if (self.native is not None and self.active) else ctypes.c_void_p(0)
         core = lib.dpa_reducer_create(comm_h, ctypes.c_void_p(self.store.g.data_ptr()), n, bo, nb, lo, hi)
         if not core:
             raise RuntimeError("dpa_reducer_create failed (bucket plan out of range)")
@@ -122,6 +119,14 @@ class GradReducer:
     # ------------------------------------------------------------------ wrap-time sync (X2, X3)
     def _verify_and_broadcast(self):
         sig = hashlib.sha1(repr([(s.name, s.logical_shape, s.trainable) for s in self.store.params]).encode()).digest()[:8]
+        if self.native is not None:
+            for r, other in enumerate(self.native.all_gather_bytes(sig, "layout")):
+                if other != sig:
+                    raise RuntimeError(f"parameter layout differs between rank {self.rank} and rank {r}")
+            for t in (self.store.p, self.store.b, self.store.nbt):
+                self.native.broadcast(t, 0)
+            self.store.refresh_compute_copy()
+            return
         mine = torch.tensor(list(sig), dtype=torch.int64, device=self.store.device)
         allsig = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(allsig, mine, group=self.pg)
@@ -136,7 +141,7 @@ class GradReducer:
     # ------------------------------------------------------------------ per step
     def sync_buffers(self):
         """DDP's per-forward buffer broadcast (X4): rank 0's BatchNorm running statistics overwrite everyone's."""
-        if (self.world > 1 or self.force) and self.broadcast_buffers and self.store.b_size > 0:
+        if self.active and self.broadcast_buffers and self.store.b_size > 0:
             if self.native is not None:
                 self.native.broadcast(self.store.b, 0)
                 self.native.broadcast(self.store.nbt, 0)
@@ -153,13 +158,17 @@ class GradReducer:
         bi = self._core_lib.dpa_reducer_param_ready(self._core, spec.index, self._stream())
         if bi >= 0:
             if self.native is not None:
-                self._works[bi] = "native"        # the core enqueued ncclAllReduce on the comm stream
+                if self.active:
+                    self._works[bi] = "native"    # the core enqueued the all-reduce on the communicator's stream
+                    if self.sync_mode:            # debug: the collective finishes before backward continues
+                        self.native.sync()
             else:
                 self._launch(bi)
         elif bi == -2:
             raise RuntimeError(f"reducer protocol error: gradient of {spec.name} reported ready twice in one backward")
         elif bi == -3:
-            raise RuntimeError(f"RCCL all-reduce could not be enqueued for the bucket of {spec.name}")
+            detail = self.native.last_error() if self.native is not None else ""
+            raise RuntimeError(f"all-reduce could not be enqueued for the bucket of {spec.name}: {detail}")
 
     def _launch(self, bi):
         """torch.distributed backend (RCCL process group on GPUs, gloo on CPUs): async all-reduce of bucket bi."""
@@ -182,7 +191,8 @@ class GradReducer:
                 raise RuntimeError(f"bucket {bi} never became ready: {missing} gradients missing "
                                    f"(a trainable parameter did not take part in backward)")
             if rc != 0:
-                raise RuntimeError(f"waiting for the all-reduce of bucket {bi} failed")
+                detail = self.native.last_error() if self.native is not None else ""
+                raise RuntimeError(f"waiting for the all-reduce of bucket {bi} failed on rank {self.rank}: {detail}")
             w = self._works[bi]
             if w is not None and w != "native":
                 w.wait()                       # stream-level wait on GPU; blocks on gloo
@@ -192,9 +202,14 @@ class GradReducer:
     # ------------------------------------------------------------------ diagnostics
     def check_in_sync(self):
         """All ranks must hold bit-identical parameters; returns the max deviation of the checksum (0.0 if in sync)."""
-        if self.world == 1 and not self.force:
+        if not self.active:
             return 0.0
         cs = torch.stack([self.store.p.double().sum(), self.store.p.double().abs().sum()])
+        if self.native is not None:
+            vals = cs.tolist()
+            lo = self.native.all_reduce_scalars(vals, "min")
+            hi = self.native.all_reduce_scalars(vals, "max")
+            return max(abs(h - l) for h, l in zip(hi, lo))
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)

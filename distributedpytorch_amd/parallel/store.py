@@ -20,10 +20,12 @@ class TCPStore:
         lib.dpa_store_server_start.restype = ctypes.c_void_p
         lib.dpa_store_connect.restype = ctypes.c_void_p
         lib.dpa_store_add.restype = ctypes.c_longlong
+        lib.dpa_store_last_size.restype = ctypes.c_longlong
+        lib.dpa_store_last_copy.restype = ctypes.c_longlong
         self._lib, self._server = lib, None
         self.timeout_s = timeout_s
         if is_master:
-            self._server = lib.dpa_store_server_start(int(port))
+            self._server = lib.dpa_store_server_start(host.encode(), int(port))
             if not self._server:
                 raise RuntimeError(f"cannot bind rendezvous store on port {port}")
             port = lib.dpa_store_server_port(ctypes.c_void_p(self._server))
@@ -43,6 +45,13 @@ class TCPStore:
         n = self._lib.dpa_store_get(ctypes.c_void_p(self._client), key.encode(), buf, len(buf), ctypes.c_longlong(ms))
         if n == -1:
             raise StoreTimeout(f"key {key!r} not set within {ms / 1000:.1f}s")
+        if n == -5:         # larger than the first buffer: the client kept it
+            size = int(self._lib.dpa_store_last_size(ctypes.c_void_p(self._client)))
+            big = ctypes.create_string_buffer(size)
+            got = int(self._lib.dpa_store_last_copy(ctypes.c_void_p(self._client), big, ctypes.c_longlong(size)))
+            if got != size:
+                raise RuntimeError(f"store get({key}) failed while fetching a {size}-byte value")
+            return big.raw[:size]
         if n < 0:
             raise RuntimeError(f"store get({key}) failed rc={n}")
         return buf.raw[:n]
@@ -52,6 +61,9 @@ class TCPStore:
         if v == -(2 ** 63):
             raise RuntimeError(f"store add({key}) failed")
         return int(v)
+
+    def delete(self, key) -> bool:
+        return self._lib.dpa_store_delete(ctypes.c_void_p(self._client), key.encode()) == 0
 
     def check(self, key) -> bool:
         return self._lib.dpa_store_check(ctypes.c_void_p(self._client), key.encode()) == 0

@@ -71,21 +71,36 @@ def processData(gpu, phase, epoch, dmodel: DistributedModel, modelName, dataset,
     nbIters = len(it)
     lastLog = 0
     dmodel.reset_epoch_metrics()
-    graph_ok = train and cfg is not None and getattr(cfg, "USE_HIPGRAPH", False) and dmodel.device.type == "cuda" \
-        and dmodel.reducer.world == 1
-    for i, (inputs, labels) in enumerate(it):
+    graph_ok = train and cfg is not None and getattr(cfg, "USE_HIPGRAPH", False) and dmodel.can_capture()
+    steplog = dmodel.steplog if train else None
+    batches = iter(it)
+    i = -1
+    while True:
+        if steplog is not None:
+            steplog.begin(step0 + i + 1, epoch)
+        try:
+            inputs, labels = next(batches)
+        except StopIteration:
+            break
+        i += 1
         if train:
+            if steplog is not None:
+                steplog.mark("data")
             if cfg is not None:
                 _maybe_fault(cfg, rank, step0 + i)
             if graph_ok and inputs.shape[0] == dataset.batchSize:
                 if dmodel._graph is None:
                     dmodel.capture_train_step(inputs, labels)
                 dmodel.replay_train_step(inputs, labels)
+                if steplog is not None:
+                    steplog.mark("graph")           # the phases live inside the replayed hipGraph
             else:
-                dmodel.train_step(inputs, labels)
+                dmodel.train_step(inputs, labels, mark=steplog.mark if steplog is not None else None)
+            if steplog is not None:
+                steplog.end(dmodel.metrics, inputs.shape[0])
             if _NATIVE and i % 50 == 49 and _NATIVE[-1].async_error() != 0:      # ncclCommGetAsyncError
                 _NATIVE[-1].abort()
-                raise RuntimeError(f"RCCL reported an asynchronous error on rank {rank}; communicator aborted")
+                raise RuntimeError(f"communicator reported an asynchronous error on rank {rank}; aborted")
         else:
             dmodel.eval_step(inputs, labels)
         if gpu <= 0 and train:
@@ -96,11 +111,14 @@ def processData(gpu, phase, epoch, dmodel: DistributedModel, modelName, dataset,
                 lastLog = n // 10
                 loss, _, cnt = dmodel.epoch_metrics()
                 logging.info(f"\repoch:{epoch:03d} nb batches:{i + 1:04d} mean train loss:{loss:.5f}")
+                if steplog is not None:
+                    steplog.flush()
     loss, acc, cnt = dmodel.epoch_metrics()
+    if steplog is not None:
+        steplog._cur = None
+        steplog.flush()
     if cfg is not None and getattr(cfg, "GLOBAL_METRICS", False) and comm.is_distributed():
-        t = torch.tensor([loss, acc], device=dmodel.device, dtype=torch.float64)
-        torch.distributed.all_reduce(t)
-        loss, acc = (t / comm.world_size()).tolist()
+        loss, acc = (v / comm.world_size() for v in comm.all_reduce_scalars([loss, acc], "sum", dmodel.device))
     return loss, acc
 
 
@@ -109,9 +127,9 @@ def _build(args, gpu, rank, modelName, cfg, with_optimizer):
     dtype = _dtype(cfg, device)
     if device.type == "cuda" and dtype == torch.float32:
         from .ops.native import set_fp32_mode
-        set_fp32_mode(getattr(cfg, "FP32_MODE", "exact"))
-        if rank == 0 and getattr(cfg, "FP32_MODE", "exact") != "exact":
-            logging.info(f"fp32 convolution arithmetic: {cfg.FP32_MODE}")
+        set_fp32_mode(getattr(cfg, "FP32_MODE", "x6"))
+        if rank == 0:
+            logging.debug(f"fp32 convolution arithmetic: {getattr(cfg, 'FP32_MODE', 'x6')}")
     dataset = MNIST(args.dataPath, args.batchSize, get_model_input_size(modelName), worldSize=args.worldSize, rank=rank,
                     gpu=gpu, device=device, dtype=dtype, debug=bool(args.debug), seed=cfg.SEED,
                     synthetic_ok=getattr(cfg, "SYNTHETIC_DATA", False))
@@ -141,51 +159,54 @@ def _build(args, gpu, rank, modelName, cfg, with_optimizer):
                               bucket_cap_mb=getattr(cfg, "BUCKET_CAP_MB", 25.0),
                               broadcast_buffers=getattr(cfg, "BROADCAST_BUFFERS", True),
                               sync_comm=getattr(cfg, "SYNC_COMM", False), native_comm=_NATIVE[-1] if _NATIVE else None)
+    from .utils.steplog import StepLog
+    dmodel.steplog = StepLog(os.path.join(cfg.RSL_PATH, "steps.jsonl"), device, args.worldSize, args.batchSize,
+                             enabled=with_optimizer and rank == 0 and getattr(cfg, "STEP_METRICS", True))
     return device, dataset, net, dmodel, optimizer, scheduler
 
 
+def _comm_backend(cfg):
+    b = getattr(cfg, "COMM_BACKEND", "native")
+    return "native" if b in ("native", "rccl_native", "tcp_native") else b
+
+
 def _init_dist(args, gpu, rank, cfg):
-    """Rendezvous in two stages: (1) the C++ TCP store on MASTER_PORT+1 checks that every rank of DDTNodes has arrived
-    and names the missing ones on timeout (the reference just blocks, README.md:47-49); (2) torch.distributed's
-    env:// bring-up of RCCL (GPU) or gloo (CPU) on MASTER_PORT."""
+    """Bring-up of the communication layer (X1 of SURVEY.md §2.6; /root/reference/classif.py:86-87).
+
+    COMM_BACKEND='native' (default): the C++ TCP store on MASTER_PORT+2 is the rendezvous (arrival check that NAMES
+    missing ranks - the reference just blocks, README.md:47-49 -, ncclUniqueId / mesh addresses) and ONE native
+    communicator per rank carries the data: RCCL over xGMI on GPUs, the TCP mesh on CPUs.  No process group exists.
+    COMM_BACKEND='torch': torch.distributed's env:// bring-up of RCCL (GPU) or gloo (CPU), with the store's arrival check
+    in front."""
     device = _device_for(gpu)
-    if args.worldSize > 1 or gpu >= 0:
-        if args.worldSize > 1 and getattr(cfg, "RENDEZVOUS_TIMEOUT_S", 0) > 0:
-            from .parallel.store import TCPStore
-            store = TCPStore(os.environ.get("MASTER_ADDR", cfg.MASTER_ADDR), int(os.environ.get("MASTER_PORT", cfg.MASTER_PORT)) + 1,
-                             is_master=(rank == 0), timeout_s=cfg.RENDEZVOUS_TIMEOUT_S)
-            try:
-                store.announce_and_wait(rank, args.worldSize, tag="join")
-                store.barrier(rank, args.worldSize, "joined")     # nobody tears the server down while others still poll
-            finally:
-                if rank != 0:
-                    store.close()
-            _STORES.append(store)
-        comm.init_process_group(rank, args.worldSize, device, timeout_s=getattr(cfg, "COLLECTIVE_TIMEOUT_S", 600.0))
-        if getattr(cfg, "COMM_BACKEND", "torch") == "rccl_native" and device.type == "cuda":
-            _NATIVE.append(make_native_comm(rank, args.worldSize, device,
-                                            os.environ.get("MASTER_ADDR", cfg.MASTER_ADDR),
-                                            int(os.environ.get("MASTER_PORT", cfg.MASTER_PORT)) + 2))
+    if not (args.worldSize > 1 or gpu >= 0):
+        return
+    addr = os.environ.get("MASTER_ADDR", cfg.MASTER_ADDR)
+    port = int(os.environ.get("MASTER_PORT", cfg.MASTER_PORT))
+    if _comm_backend(cfg) == "native":
+        force = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1"
+        nc = comm.init_native(rank, args.worldSize, device, addr, port, timeout_s=getattr(cfg, "COLLECTIVE_TIMEOUT_S", 600.0),
+                              rendezvous_timeout_s=getattr(cfg, "RENDEZVOUS_TIMEOUT_S", 300.0) or 300.0,
+                              create_for_single_rank=force)
+        if nc is not None:
+            _NATIVE.append(nc)
+        return
+    if args.worldSize > 1 and getattr(cfg, "RENDEZVOUS_TIMEOUT_S", 0) > 0:
+        from .parallel.store import TCPStore
+        store = TCPStore(addr, port + 1, is_master=(rank == 0), timeout_s=cfg.RENDEZVOUS_TIMEOUT_S)
+        try:
+            store.announce_and_wait(rank, args.worldSize, tag="join")
+            store.barrier(rank, args.worldSize, "joined")     # nobody tears the server down while others still poll
+        finally:
+            if rank != 0:
+                store.close()
+        _STORES.append(store)
+    comm.init_process_group(rank, args.worldSize, device, timeout_s=getattr(cfg, "COLLECTIVE_TIMEOUT_S", 600.0))
 
 
 def make_native_comm(rank, world, device, addr, port, timeout_s=300.0):
-    """The C++ RCCL communicator (csrc/comm/rccl_comm.cpp): rank 0 creates the ncclUniqueId and publishes it through
-    the C++ TCP store (N1), every rank joins with ncclCommInitRank.  World size 1 needs no store."""
-    from .parallel.rccl_native import NativeRcclComm
-    store = None
-    if world > 1:
-        from .parallel.store import TCPStore
-        store = TCPStore(addr, port, is_master=(rank == 0), timeout_s=timeout_s)
-    try:
-        nc = NativeRcclComm(store, rank, world, device.index or 0)
-        if store is not None:
-            store.barrier(rank, world, "rccl_up")
-    finally:
-        if store is not None and rank != 0:
-            store.close()
-    if store is not None and rank == 0:
-        _STORES.append(store)
-    return nc
+    """The native communicator for callers outside the trainer (bench.py, tests): store on `port` + the offset."""
+    return comm.init_native(rank, world, device, addr, port, timeout_s=timeout_s, create_for_single_rank=True)
 
 
 _STORES = []
@@ -262,20 +283,13 @@ def train(gpu, args):
                                          valid_acc=validAcc, images_per_s=ips, seconds=endTime - startEpochTime,
                                          world_size=args.worldSize))
     finally:
-        comm.destroy_process_group()
         _close_stores()
 
 
 def _close_stores():
-    while _NATIVE:
-        try:
-            nc = _NATIVE.pop()
-            if nc.async_error() != 0:
-                nc.abort()
-            else:
-                nc.destroy()
-        except Exception:       # noqa: BLE001 - shutdown path
-            pass
+    _NATIVE.clear()
+    # native communicator + its store (with a farewell barrier unless an exception is on its way out), or the process group
+    comm.shutdown(clean=sys.exc_info()[0] is None)
     while _STORES:
         try:
             _STORES.pop().close()
@@ -311,5 +325,4 @@ def test(gpu, args):
             logging.info(f"Time: {mins}m {secs}s, Acc: {acc * 100:.2f}%")
         return acc
     finally:
-        comm.destroy_process_group()
         _close_stores()

@@ -18,3 +18,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["x6", "exact"])
+def fp32_mode(request):
+    """Run a GPU kernel test under both fp32 convolution arithmetics (x6 is the default, exact the alternative)."""
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    prev = set_fp32_mode(request.param)
+    yield request.param
+    set_fp32_mode(prev)

@@ -36,8 +36,10 @@ def _tol(dtype, kred):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_conv_fprop_dgrad_wgrad(shape, dtype):
+def test_conv_fprop_dgrad_wgrad(shape, dtype, fp32_mode):
     from distributedpytorch_amd.ops import hip_conv
+    if dtype == torch.bfloat16 and fp32_mode == "exact":
+        pytest.skip("the fp32 arithmetic mode does not affect the bf16 kernels")
     N, H, W, C, K, k, s, pd = shape
     g = torch.Generator(device="cuda").manual_seed(1234)
     x = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
@@ -96,7 +98,7 @@ def test_conv_channel_slice_and_epilogue():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv_splitk_skinny_gemm(dtype):
+def test_conv_splitk_skinny_gemm(dtype, fp32_mode):
     """Linear-shaped problems (few output tiles, long reduction) take the split-K path: partial sums in a workspace,
     bias + addend + ReLU in the reduce kernel.  Compared with the same op forced through the single-pass kernel's
     reference (plain fp32 matmul)."""

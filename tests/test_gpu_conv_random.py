@@ -28,7 +28,7 @@ def _cases(seed, n):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv_random_geometries(dtype):
+def test_conv_random_geometries(dtype, fp32_mode):
     from distributedpytorch_amd.ops import hip_conv
     g = torch.Generator(device="cuda").manual_seed(99)
     for (N, H, W, C, K, k, s, pd) in _cases(1234, 40):

@@ -105,40 +105,7 @@ def test_graft_smoke():
     ge.smoke()
 
 
-def test_native_rccl_comm_world1_matches_plain():
-    """The native RCCL communicator (own HIP comm stream, hipEvent fencing) at world_size 1: all-reduce over one rank
-    is the identity, so training must be bit-identical to the plain path - this exercises ncclCommInitRank,
-    the bucket launch order and the stream/event protocol on real hardware."""
-    from distributedpytorch_amd.models.factory import get_model
-    from distributedpytorch_amd.nn.loss import Criterion
-    from distributedpytorch_amd.nn.optim import ArenaOptimizer
-    from distributedpytorch_amd.parallel.ddp import DistributedModel
-    from distributedpytorch_amd.parallel.rccl_native import NativeRcclComm
-    comm = NativeRcclComm(None, 0, 1, 0)
-    try:
-        nets = []
-        for native in (None, comm):
-            torch.manual_seed(0)
-            net, _ = get_model("resnet", 10, device="cuda", dtype=torch.bfloat16)
-            dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3), first_bucket_mb=0.25,
-                                  bucket_cap_mb=4.0, native_comm=native)
-            assert len(dm.reducer.buckets) > 4
-            x, y = _batch(16, 64, net.in_channels, torch.bfloat16)
-            for _ in range(3):
-                dm.train_step(x, y)
-            torch.cuda.synchronize()
-            nets.append(net.store.p.clone())
-        assert comm.async_error() == 0
-        assert torch.equal(nets[0], nets[1])
-    finally:
-        comm.destroy()
-
-
-def test_torch_rccl_collectives_world1_match_plain():
-    """The default DDP backend on real hardware: a 1-rank RCCL process group with DPA_FORCE_COLLECTIVES=1 issues every
-    collective of the multi-GPU path (layout all-gather, wrap-time and per-step broadcasts, async bucket all-reduce,
-    wait + per-bucket optimizer).  Over one rank they are identities, so training must match the plain path bit for bit."""
-    script = r'''
+_W1_SCRIPT = r'''
 import os, sys, torch
 sys.path.insert(0, os.environ["DPA_ROOT"])
 from distributedpytorch_amd.models.factory import get_model
@@ -147,34 +114,112 @@ from distributedpytorch_amd.nn.optim import ArenaOptimizer
 from distributedpytorch_amd.parallel import comm
 from distributedpytorch_amd.parallel.ddp import DistributedModel
 force = os.environ.get("DPA_FORCE_COLLECTIVES") == "1"
+backend = os.environ["BACKEND"]
+graph = os.environ.get("GRAPH") == "1"
 torch.cuda.set_device(0)
-if force:
+torch.cuda.set_stream(torch.cuda.Stream())
+nc = None
+if force and backend == "native":
+    nc = comm.init_native(0, 1, torch.device("cuda", 0), "127.0.0.1", 29577, create_for_single_rank=True)
+    assert nc.name == "rccl_native" and not torch.distributed.is_initialized()      # ONE communicator, no process group
+elif force:
     comm.init_process_group(0, 1, torch.device("cuda", 0), timeout_s=60)
 torch.manual_seed(0)
 net, _ = get_model("resnet", 10, device="cuda", dtype=torch.bfloat16)
-dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3), first_bucket_mb=0.25, bucket_cap_mb=4.0)
-assert dm.reducer.force == force and len(dm.reducer.buckets) > 4
+dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3), first_bucket_mb=0.25, bucket_cap_mb=4.0,
+                      native_comm=nc)
+assert dm.reducer.force == force and dm.reducer.active == force and len(dm.reducer.buckets) > 4
 g = torch.Generator(device="cuda").manual_seed(3)
 x = torch.zeros(16, 64, 64, net.in_channels, device="cuda", dtype=torch.bfloat16)
 x[..., :3] = torch.randn(16, 64, 64, 3, device="cuda", generator=g).to(torch.bfloat16)
 y = torch.randint(0, 10, (16,), device="cuda", generator=g)
-for _ in range(3):
-    dm.train_step(x, y)
+if graph:
+    assert dm.capture_train_step(x, y), "capture refused"
+    for _ in range(3):
+        dm.replay_train_step(x, y)
+else:
+    for _ in range(3):
+        dm.train_step(x, y)
 torch.cuda.synchronize()
 torch.save(net.store.p.cpu(), sys.argv[1])
 if force:
     assert dm.reducer.check_in_sync() == 0.0
-    comm.destroy_process_group()
+    if nc is not None:
+        assert nc.async_error() == 0 and nc.inflight() == 0
+        launched = dm.reducer._core_lib.dpa_reducer_launched_bytes(dm.reducer._core)
+        assert launched >= 3 * dm.reducer.comm_bytes
+    comm.shutdown()
 '''
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "w1.py")
-        open(path, "w").write(script)
-        outs = []
-        for force in ("0", "1"):
-            out = os.path.join(d, f"p{force}.pt")
-            env = dict(os.environ, DPA_ROOT=ROOT, DPA_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-            r = subprocess.run([sys.executable, path, out], env=env, capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-            outs.append(torch.load(out))
-        assert torch.equal(outs[0], outs[1])
+
+
+def _run_w1(tmpdir, tag, **env_extra):
+    path = os.path.join(tmpdir, "w1.py")
+    open(path, "w").write(_W1_SCRIPT)
+    out = os.path.join(tmpdir, f"p_{tag}.pt")
+    env = dict(os.environ, DPA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", **env_extra)
+    r = subprocess.run([sys.executable, path, out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return torch.load(out)
+
+
+@pytest.mark.parametrize("backend", ["native", "torch"])
+def test_forced_collectives_world1_match_plain(backend, tmp_path):
+    """DPA_FORCE_COLLECTIVES=1 issues every collective of the multi-GPU path on ONE rank of real RCCL (layout exchange,
+    wrap-time and per-step broadcasts, async bucket all-reduce on the comm stream with hipEvent fencing, wait + per-bucket
+    optimizer).  Over one rank they are identities, so training must match the plain path bit for bit.
+    backend='native' (the default path): the C++ communicator, and NO torch.distributed process group underneath;
+    backend='torch': the fallback path through ProcessGroupNCCL."""
+    plain = _run_w1(str(tmp_path), "plain", DPA_FORCE_COLLECTIVES="0", BACKEND=backend)
+    forced = _run_w1(str(tmp_path), "forced", DPA_FORCE_COLLECTIVES="1", BACKEND=backend)
+    assert torch.equal(plain, forced)
+
+
+def test_hipgraph_capture_with_native_collectives_matches_eager(tmp_path):
+    """hipGraph for world > 1 (SURVEY.md §7.4 item 7): the whole iteration INCLUDING the communicator's event fencing
+    and ncclAllReduce / ncclBroadcast on the comm stream is captured (RCCL supports stream capture) and replayed; at
+    world size 1 with forced collectives the replay must equal the eager run bit for bit."""
+    eager = _run_w1(str(tmp_path), "eager", DPA_FORCE_COLLECTIVES="1", BACKEND="native", GRAPH="0")
+    replay = _run_w1(str(tmp_path), "graph", DPA_FORCE_COLLECTIVES="1", BACKEND="native", GRAPH="1")
+    assert torch.equal(eager, replay)
+
+
+def _shared_gpu_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.parallel import comm
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream())
+    nc = comm.init_native(rank, world, torch.device("cuda", 0), "127.0.0.1", port, timeout_s=120, transport="tcp")
+    assert nc.name == "tcp_native"
+    torch.manual_seed(100 + rank)                               # wrap-time broadcast must make the ranks identical
+    net, _ = get_model("resnet", 10, device="cuda", dtype=torch.bfloat16)
+    dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3), first_bucket_mb=0.25,
+                          bucket_cap_mb=4.0, native_comm=nc)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.zeros(16, 64, 64, net.in_channels, device="cuda", dtype=torch.bfloat16)
+    x[..., :3] = torch.randn(16, 64, 64, 3, device="cuda", generator=g).to(torch.bfloat16)
+    y = torch.randint(0, 10, (16,), device="cuda", generator=g)
+    grads = []
+    for _ in range(3):
+        dm.train_step(x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8])
+        grads.append(net.store.g.clone().cpu())
+    torch.cuda.synchronize()
+    assert dm.reducer.check_in_sync() == 0.0
+    torch.save({"p": net.store.p.cpu(), "g": grads}, os.path.join(out_dir, f"sg{rank}.pt"))
+    comm.shutdown()
+
+
+def test_two_ranks_share_one_gpu_through_the_staged_tcp_transport(tmp_path):
+    """World size 2 ON the GPU: RCCL refuses two ranks on one device, so the rehearsal uses the communicator's TCP
+    transport with device buffers staged through pinned memory - the same front (slot ring, bucket map), the same
+    reducer core, real ready/done hipEvents between the compute stream and the transport's stream, real kernels."""
+    import torch.multiprocessing as mp
+    mp.spawn(_shared_gpu_worker, nprocs=2, args=(2, 29611, str(tmp_path)), join=True)
+    r0, r1 = torch.load(tmp_path / "sg0.pt"), torch.load(tmp_path / "sg1.pt")
+    assert torch.equal(r0["p"], r1["p"])
+    for a, b in zip(r0["g"], r1["g"]):
+        assert torch.equal(a, b)

@@ -232,24 +232,29 @@ def test_x6_subnormal_inf_nan_propagation():
     N, H, W, C, K, k = 4, 14, 14, 256, 128, 3
     g = torch.Generator(device="cuda").manual_seed(5)
     w = torch.randn(K, k, k, C, device="cuda", generator=g)
+    x_low = torch.randn(N, H, W, C, device="cuda", generator=g) * 1e-30        # low end of the normal range
     x_tiny = torch.randn(N, H, W, C, device="cuda", generator=g) * 1e-38       # mixes subnormals and tiny normals
     x_tiny[0, :, :, ::2] *= 1e-4                                                # deep subnormals (1e-42)
     x_clean = torch.randn(N, H, W, C, device="cuda", generator=g)
+    wd = w.permute(0, 3, 1, 2).double()
     prev = set_fp32_mode("exact")
     try:
-        outs = {}
-        for mode in ("exact", "x6"):
-            set_fp32_mode(mode)
-            y = torch.empty(N, H, W, K, device="cuda")
-            hip_conv.conv_fprop(x_tiny, w, y, (1, 1), (1, 1))
-            assert torch.isfinite(y).all(), mode
-            outs[mode] = y.double()
-        ref = F.conv2d(x_tiny.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
-        scale = F.conv2d(x_tiny.permute(0, 3, 1, 2).double().abs(), w.permute(0, 3, 1, 2).double().abs(), padding=1).permute(0, 2, 3, 1)
-        # gradual underflow: results near 1e-36 keep their relative accuracy, contributions below 2^-149 may flush
-        for mode in ("exact", "x6"):
-            err = ((outs[mode] - ref).abs() - 1e-43 * k * k * C).clamp_min(0) / scale
-            assert err.max().item() < 1e-5, (mode, err.max().item())
+        # bound per element, relative to sum |a||b|:
+        #   1e-30: both modes at fp32 accuracy (the remainders 2^-8 and 2^-16 below the value are still normal numbers);
+        #   1e-38 and below: the exact path keeps fp32's gradual underflow; x6's remainders fall under the smallest
+        #   normal number and are lost one after the other, so its accuracy degrades gracefully towards the leading
+        #   bf16 part (2^-8) - finite, never NaN.  Magnitudes below ~1e-33 do not occur in training (docs/ARCHITECTURE.md).
+        for xin, bounds in ((x_low, {"exact": 1e-5, "x6": 4e-7}), (x_tiny, {"exact": 1e-5, "x6": 2.0 ** -7})):
+            ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), wd, padding=1).permute(0, 2, 3, 1)
+            scale = F.conv2d(xin.permute(0, 3, 1, 2).double().abs(), wd.abs(), padding=1).permute(0, 2, 3, 1)
+            for mode in ("exact", "x6"):
+                set_fp32_mode(mode)
+                y = torch.empty(N, H, W, K, device="cuda")
+                hip_conv.conv_fprop(xin, w, y, (1, 1), (1, 1))
+                assert torch.isfinite(y).all(), mode
+                # (contributions below the smallest subnormal, 2^-149, may flush in either mode)
+                err = ((y.double() - ref).abs() - 1e-43 * k * k * C).clamp_min(0) / scale
+                assert err.max().item() < bounds[mode], (mode, err.max().item())
         for bad in (float("inf"), float("-inf"), float("nan")):
             for mode in ("exact", "x6"):
                 set_fp32_mode(mode)
