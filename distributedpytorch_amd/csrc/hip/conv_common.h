@@ -37,6 +37,9 @@ struct ConvParams {
   const void* addend; // optional tensor with dst geometry added in the epilogue (dgrad accumulation) or null
   const float* stats_shift; // [dC] or null: the slab holds sum(v - c), sum((v - c)^2) about this per-channel shift c
                             // (shifted-data variance: no cancellation when |mean| >> std, see bn_finalize_kernel)
+  const void* wgt3;  // fp32 x6 fast path: the filter pre-split into three bf16 planes [3][dC][R][S][sC] in "x6 plane
+                     // order" (split3_planes_kernel), or null
+  long long wgt3_plane;  // elements per plane
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;
@@ -57,6 +60,7 @@ struct ConvParams {
   int base_y, base_x;      // source coordinate of class pixel 0 under tap 0 of the class
   int tap_r0, tap_s0;      // first tap of the class
   int nR, nS;              // taps of the class along each dim      (fprop: R, S)
+  int stats_rows_used;     // OUT (host): rows of the stats slab this launch wrote (depends on the tile plan)
   FastDiv fd_nW, fd_nH, fd_sC, fd_nS;
 };
 

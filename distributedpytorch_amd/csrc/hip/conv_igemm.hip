@@ -533,12 +533,18 @@ static int x6_reg() {       // x6 also for the register-staged (short reduction)
   return v;
 }
 
+// rows of the stats slab written by the launches of the current dpa_conv_igemm call (reported back in ConvParams)
+static thread_local int g_stats_rows = 0;
+bool dpa_x6p_eligible(const ConvParams& p);                       // conv_x6p.hip
+int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s);
+
 template <typename T, int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   ConvParams p = pin;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   p.tilesM = (p.M - p.m_off + BM - 1) / BM;
   p.tilesN = (p.dC + BN - 1) / BN;
+  if (p.stats_row0 + p.tilesM > g_stats_rows) g_stats_rows = p.stats_row0 + p.tilesM;
   // staging policy: LDS-DMA + 2 stage buffers pays when there are enough K-tiles to pipeline; short reductions
   // (1x1 convs on few channels) run more blocks per CU with the single-buffer register-staged variant.
   static const int no_uni = [] { const char* e = getenv("DPA_CONV_UNI"); return (e && e[0] == '0') ? 1 : 0; }();
@@ -666,6 +672,14 @@ static void launch_tiles(ConvParams& p, int dgrad, hipStream_t s) {
   // tile selection: narrow outputs get a tall tile; small problems get small tiles so that the grid
   // still covers the 256 CUs.
   p.m_off = 0; p.stats_row0 = 0;
+  if constexpr (sizeof(T) == 4) {
+    // fp32, x6 arithmetic, filter available as pre-split planes: the kernel whose B operand costs no VALU (conv_x6p.hip)
+    if (fp32_x6() && dpa_x6p_eligible(p)) {
+      const int rows = dpa_x6p_launch(p, dgrad, s);
+      if (rows > g_stats_rows) g_stats_rows = rows;
+      return;
+    }
+  }
   const long long big_tiles = (long long)((p.M + 127) / 128) * ((p.dC + 127) / 128);
   if (p.dC <= 32)                     launch_cfg<T, 4, 1, 2, 2>(p, dgrad, s);   // 128 x 32
   else if (p.dC <= 64) {
@@ -738,7 +752,9 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
 // dtype: 0 = fp32, 1 = bf16.  Returns 0 on success, non-zero for an unsupported geometry.
 DPA_API int dpa_conv_igemm(ConvParams* p, int dtype, int dgrad, hipStream_t s) {
   ConvParams q = *p;
+  g_stats_rows = 0;
   const int rc = dtype == 1 ? launch_conv<bf16_t>(q, dgrad, s) : launch_conv<float>(q, dgrad, s);
+  p->stats_rows_used = g_stats_rows;
   if (rc) return rc;                       // 1, 2: unsupported geometry (nothing was launched)
   const int e = dpa_launch_rc();           // a rejected launch (LDS size, grid size, ...) must not pass silently
   return e ? 1000 + e : 0;

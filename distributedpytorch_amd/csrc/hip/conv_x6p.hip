@@ -1,0 +1,324 @@
+// fp32 convolution forward / data-gradient through the bf16 matrix pipe with PRE-SPLIT weights ("x6p").
+//
+// x6 arithmetic (conv_common.h): every fp32 value is the exact sum of three bf16 parts, a product is six bf16 x bf16
+// MFMA products with fp32 accumulation.  The general x6 kernel (conv_igemm.hip) splits BOTH operands after every LDS
+// fragment read - 343 VALU instructions next to 96 MFMAs per K-tile and wave, and on this part VALU time adds to MFMA
+// time (profiles/r1_micro_valu_mfma_coissue.txt), so it ran at half the matrix rate.  Here:
+//   * the filter is split ONCE per step into three bf16 planes (split3_planes_kernel below) and staged as planes, so
+//     the B operand costs no VALU at all;
+//   * the four waves of a block are stacked along M (WM = 4, WN = 1): a wave owns 32 rows x the whole tile width, so
+//     each activation fragment is split once and used against TN = 8 (4) filter fragments - 2 splits per 96 (48) MFMAs.
+// What remains is ~80 VALU instructions per K-tile and wave: the kernel is bound by the bf16 MFMA rate / 6.
+//
+// Staging: LDS-DMA (global_load_lds_dwordx4), two stage buffers, one barrier per K-tile, like the GLDS path of
+// conv_igemm.hip.  A (activations, fp32): 128 rows x 128 B, chunk ^ ((row >> 1) & 7) swizzle.  B: three planes of
+// BN rows x 64 B (32 bf16 of the reduction), 16-byte slot ^ ((-(row >> 2)) & 3) swizzle - conflict-free for the
+// ds_read_b128 lane groups of the 16x16x32 fragment (derivation in docs/KERNELS.md).
+// Only the uniform-tap address path (Cin % 32 == 0: every layer of the zoo but the stems) - other shapes keep the
+// general kernel.
+//
+// "x6 plane order": inside every group of 32 consecutive reduction elements the planes store element
+// k = (j < 4 ? 4 q + j : 16 + 4 q + j - 4) at position 8 q + j (q = 0..3, j = 0..7), which is the order in which a lane
+// of the A fragment holds its 8 fp32 values (chunks q and 4 + q of the 128-byte row), so one ds_read_b128 of a plane is
+// one MFMA operand.
+#include "conv_common.h"
+
+__device__ uint4 dpa_zero_chunk_x6p[4];
+
+__device__ __forceinline__ void split3_frag(const uint4& lo, const uint4& hi, uint4 (&pl)[3]) {
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t o[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split3_pair(__uint_as_float(w[2 * q]), __uint_as_float(w[2 * q + 1]), o[q]);
+#pragma unroll
+  for (int part = 0; part < 3; ++part) pl[part] = make_uint4(o[0][part], o[1][part], o[2][part], o[3][part]);
+}
+
+// n fp32 values (n % 32 == 0) -> three bf16 planes of n values each, in x6 plane order.  One thread per 8 outputs.
+__global__ void __launch_bounds__(256) split3_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long long n) {
+  const long long nchunks = n >> 3;
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
+    const long long g = c >> 2; const int q = (int)(c & 3);          // group of 32, output chunk q
+    const float4 lo = *reinterpret_cast<const float4*>(w + g * 32 + 4 * q);
+    const float4 hi = *reinterpret_cast<const float4*>(w + g * 32 + 16 + 4 * q);
+    uint4 pl[3];
+    split3_frag(make_uint4(__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)),
+                make_uint4(__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)), pl);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(out + (long long)part * n + c * 8) = pl[part];
+  }
+}
+DPA_API int dpa_split3_planes(const float* w, void* out, long long n, hipStream_t s) {
+  if (n <= 0 || (n & 31)) return 1;
+  hipLaunchKernelGGL(split3_planes_kernel, dim3(dpa_grid(n / 8, 256)), dim3(256), 0, s, w, (bf16_t*)out, n);
+  return dpa_launch_rc();
+}
+
+// NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
+// 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
+template <int TN, bool DGRAD, int NW>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2)) conv_x6p_kernel(const ConvParams p) {
+  constexpr int TM = 2, BM = 32 * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
+  constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
+  constexpr int STAGE_BYTES = A_BYTES + 3 * BP_BYTES;
+  constexpr int RPP = NT / 8;                      // rows staged per pass (8 threads per 128-byte row)
+  constexpr int A_PASSES = BM / RPP;               // = 4
+  constexpr int B_PIECES = (3 * TN + NW - 1) / NW; // 1-KiB pieces (16 rows x 64 B of one plane) staged by each wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.tilesM * p.tilesN;
+  const int tile = xcd_remap((int)blockIdx.x, ntiles);
+  const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+  const int m0 = p.m_off + tm * BM, n0 = tn * BN;
+  const float* __restrict__ src = reinterpret_cast<const float*>(p.src);
+  const bf16_t* __restrict__ wgt3 = reinterpret_cast<const bf16_t*>(p.wgt3);
+
+  // ---- A operand: this thread stages the chunk that lands in slot tid & 7 of rows (tid >> 3) + 32 i -------------------
+  const int row0 = tid >> 3;
+  const int ck = (tid & 7) ^ ((row0 >> 1) & 7);
+  const int ntaps = p.nR * p.nS;
+  long long a_rowoff[A_PASSES];
+  uint32_t a_mask[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + row0 + RPP * i;
+    a_mask[i] = 0; a_rowoff[i] = 0;
+    if (m < p.M) {
+      const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+      const int xo = m - (int)t1 * p.cls_nw;
+      const uint32_t img = fd_div(t1, p.fd_nH);
+      const int yo = (int)t1 - (int)img * p.cls_nh;
+      const int y0 = DGRAD ? yo + p.base_y : yo * p.sh - p.ph;
+      const int x0 = DGRAD ? xo + p.base_x : xo * p.sw - p.pw;
+      a_rowoff[i] = ((long long)img * (p.sH * p.sW) + (long long)y0 * p.sW + x0) * p.s_cs + p.s_co + ck * 4;
+      uint32_t mk = 0;
+      for (int t = 0; t < ntaps; ++t) {
+        const int r = (int)fd_div((uint32_t)t, p.fd_nS), s_ = t - r * p.nS;
+        const int sy = DGRAD ? y0 - r : y0 + r;
+        const int sx = DGRAD ? x0 - s_ : x0 + s_;
+        if (((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW)) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
+    }
+  }
+  // ---- B operand: piece q = wave + 4 i of the K-tile: plane q / TN, rows 16 (q % TN) .. + 15; lane -> row lane >> 2,
+  //      slot lane & 3, which holds logical chunk slot ^ ((-(row >> 2)) & 3) -----------------------------------------------
+  long long b_off[B_PIECES];
+  int b_lds[B_PIECES];
+#pragma unroll
+  for (int i = 0; i < B_PIECES; ++i) {
+    const int q = wave + NW * i;                   // (3 TN is a multiple of NW for every instantiation but TN = 4, NW = 8)
+    const int plane = q / TN, r16 = q - plane * TN;
+    const int row = 16 * r16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((-(row >> 2)) & 3);
+    const int n = n0 + row;
+    // rows beyond dC alias row 0 of the filter: their output columns are never stored
+    b_off[i] = (long long)plane * p.wgt3_plane + (long long)(n < p.dC ? n : 0) * (p.R * p.S * p.sC) + chunk * 8;
+    b_lds[i] = A_BYTES + plane * BP_BYTES + r16 * 1024;
+  }
+  const float* const zero = reinterpret_cast<const float*>(dpa_zero_chunk_x6p);
+
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
+    const uint32_t k0 = (uint32_t)kt * BKE;                       // wave-uniform
+    const uint32_t tap = fd_div(k0, p.fd_sC);
+    const int cbase = (int)(k0 - tap * (uint32_t)p.sC);
+    const int r = (int)fd_div(tap, p.fd_nS);
+    const int s = (int)tap - r * p.nS;
+    const long long delta = (long long)(DGRAD ? -(r * p.sW + s) : (r * p.sW + s)) * p.s_cs + cbase;
+    const int woff = DGRAD ? (((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + cbase) : (int)k0;
+    const uint32_t bit = 1u << tap;
+    char* stage = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const float* pa = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void*)pa, (lds_void*)(stage + (i * RPP + wave * 8) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i)
+      if ((3 * TN) % NW == 0 || wave + NW * i < 3 * TN)          // wave-uniform
+        __builtin_amdgcn_global_load_lds((gbl_void*)(wgt3 + b_off[i] + woff), (lds_void*)(stage + b_lds[i]), 16, 0, 0);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (p.Kg + BKE - 1) / BKE;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b_frag = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);     // + plane * BP_BYTES + j * 1024
+  constexpr int JH = TN > 4 ? 4 : TN;                                // filter fragments held in registers at a time
+
+  if (nkt > 0) issue_tile(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* tA = smem + (kt & 1) * STAGE_BYTES;
+    const char* tB = tA + A_BYTES;
+    uint4 fa[2][TM];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * 32 + i * 16 + fr, ks * 4 + fq));
+    uint4 bp[JH][3];
+#pragma unroll
+    for (int j = 0; j < JH; ++j)
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
+    if constexpr (TN <= 4) { if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1); }
+    uint4 ap[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+    if constexpr (TN > 4) {
+      // second half of the filter fragments: read them, THEN issue the next tile's DMA (the compiler puts
+      // s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA issue), then the other 48 MFMAs
+#pragma unroll
+      for (int j = 0; j < JH; ++j)
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+          bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + (JH + j) * 1024 + b_frag);
+      if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][JH + j]);
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------- epilogue (as conv_igemm.hip, for the 4 x 1 wave arrangement) ------------
+  // acc[i][j][e] = D[row = wave*32 + i*16 + fq*4 + e][col = j*16 + fr]
+  float* __restrict__ dst = reinterpret_cast<float*>(p.dst);
+  const float* __restrict__ addend = reinterpret_cast<const float*>(p.addend);
+  constexpr int PITCH = BN + 4;
+  float* stage = reinterpret_cast<float*>(smem) + wave * (16 * PITCH);
+  float* red = reinterpret_cast<float*>(smem) + NW * 16 * PITCH;      // [NW waves][2][BN]
+  float csum[TN], csq[TN], bj[TN], cj[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + j * 16 + fr;
+    csum[j] = 0.f; csq[j] = 0.f;
+    bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
+    cj[j] = (p.stats && p.stats_shift && col < p.dC) ? p.stats_shift[col] : 0.f;
+  }
+  constexpr int LPR = BN / 4;                  // lanes per output row (16-byte chunks)
+  constexpr int RPI = 64 / LPR;                // rows per store instruction
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stage[(fq * 4 + e) * PITCH + j * 16 + fr] = acc[i][j][e] + bj[j];
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += RPI) {
+      const int r = rr + lane / LPR;
+      const int cc = (lane % LPR) * 4;
+      const int m = m0 + wave * 32 + i * 16 + r;
+      const int col = n0 + cc;
+      float4 v = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc]);
+      if (m < p.M && col < p.dC) {
+        size_t pixel = (size_t)m;
+        if (DGRAD && (p.sh != 1 || p.sw != 1)) {      // class row -> (img, hi, wi) of the full gradient tensor
+          const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+          const int jx = m - (int)t1 * p.cls_nw;
+          const uint32_t img = fd_div(t1, p.fd_nH);
+          const int iy = (int)t1 - (int)img * p.cls_nh;
+          pixel = ((size_t)img * p.dH + (size_t)(p.cls_h0 + p.sh * iy)) * p.dW + (size_t)(p.cls_w0 + p.sw * jx);
+        }
+        const size_t off = pixel * (size_t)p.d_cs + (size_t)(p.d_co + col);
+        if (addend) {
+          const float4 a = *reinterpret_cast<const float4*>(addend + off);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(dst + off) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (p.stats) {
+      const bool interior = m0 + BM <= p.M;      // block-uniform
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][e] + bj[j] - cj[j];
+          if (!interior && m0 + wave * 32 + i * 16 + fq * 4 + e >= p.M) v = 0.f;
+          csum[j] += v; csq[j] += v * v;
+        }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();                             // the staging region is reused below (block-wide)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j], q = csq[j];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (fq == 0) {
+        red[(wave * 2 + 0) * BN + j * 16 + fr] = s;
+        red[(wave * 2 + 1) * BN + j * 16 + fr] = q;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += NT) {
+      const int which = c / BN, col = c - which * BN;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * BN + col];     // fixed order: reproducible
+      if (n0 + col < p.dC) p.stats[((size_t)(p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
+    }
+  }
+}
+
+template <int TN, int NW>
+static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
+  constexpr int BN = TN * 16, BM = 32 * NW;
+  p.tilesM = (p.M - p.m_off + BM - 1) / BM;
+  p.tilesN = (p.dC + BN - 1) / BN;
+  static const int pad = [] { const char* e = getenv("DPA_X6P_LDS_PAD"); return e ? atoi(e) : 0; }();      // residency experiments
+  size_t lds = (size_t)2 * (BM * 128 + 3 * BN * 64) + pad;
+  const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
+  if (epi > lds) lds = epi;
+  const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
+  if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW>), grid, block, lds, s, p);
+  else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW>), grid, block, lds, s, p);
+}
+
+// Can this (sub-)problem take the pre-split kernel?  (called by conv_igemm.hip's launch_tiles for fp32 in x6 mode)
+bool dpa_x6p_eligible(const ConvParams& p) {
+  static const int enabled = [] { const char* e = getenv("DPA_X6P"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const int min_kt = [] { const char* e = getenv("DPA_X6P_MINKT"); return e ? atoi(e) : 2; }();
+  const int ntaps = p.nR * p.nS;
+  return enabled && p.wgt3 && (p.sC % 32 == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni && p.Kg >= 32 * min_kt && p.dC >= 16;
+}
+// Rows per M-tile the launcher will use for this problem (one stats-slab row per M-tile).
+static int x6p_waves(const ConvParams& p) {
+  static const int nw_env = [] { const char* e = getenv("DPA_X6P_WAVES"); return e ? atoi(e) : 0; }();
+  if (nw_env == 4 || nw_env == 8) return nw_env;
+  return 4;
+}
+// Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
+int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
+  p.m_off = 0; p.stats_row0 = 0;
+  const int nw = x6p_waves(p);
+  if (p.dC <= 64) { if (nw == 8) x6p_launch<4, 8>(p, dgrad, s); else x6p_launch<4, 4>(p, dgrad, s); }
+  else            { if (nw == 8) x6p_launch<8, 8>(p, dgrad, s); else x6p_launch<8, 4>(p, dgrad, s); }
+  return p.tilesM;
+}

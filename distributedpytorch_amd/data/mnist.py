@@ -74,10 +74,27 @@ def have_synthetic(root):
     return _have(synthetic_dir(root)) and os.path.exists(os.path.join(synthetic_dir(root), ".complete"))
 
 
-def generate_synthetic_mnist(root, n_train=60000, n_test=10000, seed=1234):
-    """Deterministic MNIST-shaped stand-in (there is no network to fetch the real files): ten smooth stroke
-    prototypes, one per class, with per-sample shift, scale jitter and noise, written as the four IDX files
-    torchvision.datasets.MNIST uses, under <root>/MNIST-synthetic/raw (NOT MNIST/raw: see synthetic_dir).  Each file is
+def _render_strokes(ctrl, width, T=20):
+    """ctrl: [B, P, 2] polyline control points (y, x) in pixels; width: [B] stroke sigma.  Returns [B, 28, 28] in 0..1."""
+    B, P, _ = ctrl.shape
+    t = np.linspace(0, 1, T, dtype=np.float32)[None, None, :, None]
+    pts = (ctrl[:, :-1, None, :] * (1 - t) + ctrl[:, 1:, None, :] * t).reshape(B, -1, 2)        # [B, (P-1)*T, 2]
+    yy, xx = np.mgrid[0:28, 0:28].astype(np.float32)
+    d2 = (yy[None, None] - pts[:, :, 0, None, None]) ** 2 + (xx[None, None] - pts[:, :, 1, None, None]) ** 2
+    img = np.exp(-d2 / (2 * width[:, None, None, None] ** 2)).max(1)       # max, not sum: uniform stroke intensity
+    return img
+
+
+def generate_synthetic_mnist(root, n_train=60000, n_test=10000, seed=1234, hard=False, jitter=1.0):
+    """Deterministic MNIST-shaped stand-in (there is no network to fetch the real files).
+
+    hard=False: ten smooth stroke prototypes, one per class, with per-sample shift, scale jitter and noise - separable
+    to 100 % by every implementation after one epoch (good for plumbing, useless for parity).
+    hard=True: every SAMPLE is drawn anew - the class's control points are jittered (sigma `jitter` px, comparable to the
+    distance between classes, whose prototypes share a common skeleton and differ in two control points), stroke
+    width, affine shear / scale / shift, additive clutter strokes and pixel noise vary per sample.  Classes overlap, so
+    test accuracy saturates below 100 % (a torch-eager ResNet-18 lands in the high 90s) and differences between
+    implementations show.  Written under <root>/MNIST-synthetic/raw (NOT MNIST/raw: see synthetic_dir); each file is
     written under a temporary name and renamed; the `.complete` marker comes last, and readers gate on it."""
     out_dir = synthetic_dir(root)
     os.makedirs(out_dir, exist_ok=True)
@@ -85,28 +102,60 @@ def generate_synthetic_mnist(root, n_train=60000, n_test=10000, seed=1234):
     if os.path.exists(marker):
         os.remove(marker)
     rng = np.random.RandomState(seed)
-    protos = []
-    yy, xx = np.mgrid[0:28, 0:28].astype(np.float32)
-    for c in range(10):
-        img = np.zeros((28, 28), np.float32)
-        pts = rng.uniform(6, 22, size=(4 + c % 3, 2))
-        for a, b in zip(pts[:-1], pts[1:]):
-            for t in np.linspace(0, 1, 24):
-                cy, cx = a + t * (b - a)
-                img += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.3 ** 2))
-        protos.append(np.clip(img / img.max(), 0, 1))
-    protos = np.stack(protos)
+    if hard:
+        skeleton = rng.uniform(7, 21, size=(5, 2)).astype(np.float32)
+        protos_ctrl = np.repeat(skeleton[None], 10, 0)
+        for c in range(10):                  # each class moves two of the five control points of the shared skeleton
+            which = rng.choice(5, size=2, replace=False)
+            protos_ctrl[c, which] += rng.uniform(-6.0, 6.0, size=(2, 2)).astype(np.float32)
+        protos_ctrl = np.clip(protos_ctrl, 4, 24)
 
-    def make(n, rs):
-        labels = rs.randint(0, 10, size=n).astype(np.uint8)
-        imgs = np.empty((n, 28, 28), np.uint8)
-        shifts = rs.randint(-2, 3, size=(n, 2))
-        gains = rs.uniform(0.7, 1.0, size=n).astype(np.float32)
-        for i in range(n):
-            p = np.roll(protos[labels[i]], tuple(shifts[i]), axis=(0, 1)) * gains[i]
-            p = p + rs.normal(0, 0.08, size=(28, 28)).astype(np.float32) * (p > 0.02)
-            imgs[i] = (np.clip(p, 0, 1) * 255).astype(np.uint8)
-        return imgs, labels
+        def make(n, rs):
+            labels = rs.randint(0, 10, size=n).astype(np.uint8)
+            imgs = np.empty((n, 28, 28), np.uint8)
+            for s0 in range(0, n, 256):
+                lab = labels[s0: s0 + 256]
+                b = lab.shape[0]
+                ctrl = protos_ctrl[lab] + rs.normal(0, jitter, size=(b, 5, 2)).astype(np.float32)
+                # per-sample affine about the image centre: scale, shear, shift
+                sc = rs.uniform(0.8, 1.15, size=(b, 1, 1)).astype(np.float32)
+                sh = rs.uniform(-0.25, 0.25, size=(b, 1)).astype(np.float32)
+                ctr = ctrl - 14.0
+                ctr = ctr * sc
+                ctr[:, :, 1] += sh * ctr[:, :, 0]
+                ctrl = ctr + 14.0 + rs.uniform(-2.5, 2.5, size=(b, 1, 2)).astype(np.float32)
+                img = _render_strokes(ctrl, rs.uniform(0.9, 1.7, size=b).astype(np.float32))
+                # clutter: one short random stroke of lower intensity
+                cl = rs.uniform(3, 25, size=(b, 2, 2)).astype(np.float32)
+                cl[:, 1] = cl[:, 0] + rs.uniform(-6, 6, size=(b, 2)).astype(np.float32)
+                img = np.maximum(img, 0.55 * _render_strokes(cl, np.full(b, 1.0, np.float32), T=8))
+                img = img * rs.uniform(0.6, 1.0, size=(b, 1, 1)).astype(np.float32)
+                img = img + rs.normal(0, 0.12, size=img.shape).astype(np.float32)
+                imgs[s0: s0 + b] = (np.clip(img, 0, 1) * 255).astype(np.uint8)
+            return imgs, labels
+    else:
+        protos = []
+        yy, xx = np.mgrid[0:28, 0:28].astype(np.float32)
+        for c in range(10):
+            img = np.zeros((28, 28), np.float32)
+            pts = rng.uniform(6, 22, size=(4 + c % 3, 2))
+            for a, b in zip(pts[:-1], pts[1:]):
+                for t in np.linspace(0, 1, 24):
+                    cy, cx = a + t * (b - a)
+                    img += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.3 ** 2))
+            protos.append(np.clip(img / img.max(), 0, 1))
+        protos = np.stack(protos)
+
+        def make(n, rs):
+            labels = rs.randint(0, 10, size=n).astype(np.uint8)
+            imgs = np.empty((n, 28, 28), np.uint8)
+            shifts = rs.randint(-2, 3, size=(n, 2))
+            gains = rs.uniform(0.7, 1.0, size=n).astype(np.float32)
+            for i in range(n):
+                p = np.roll(protos[labels[i]], tuple(shifts[i]), axis=(0, 1)) * gains[i]
+                p = p + rs.normal(0, 0.08, size=(28, 28)).astype(np.float32) * (p > 0.02)
+                imgs[i] = (np.clip(p, 0, 1) * 255).astype(np.uint8)
+            return imgs, labels
 
     tr_x, tr_y = make(n_train, np.random.RandomState(seed + 1))
     te_x, te_y = make(n_test, np.random.RandomState(seed + 2))

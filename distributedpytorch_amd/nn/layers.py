@@ -74,6 +74,19 @@ class Conv2d:
         self.trainable = trainable
         self._wt = None
         self._ev = None
+        self._w3 = self._wt3 = None      # the filter / transposed filter as three bf16 planes (fp32 x6 fast path)
+        self.last_stats_rows = 1
+
+    def _planes(self, ctx, w, which):
+        """w (fp32, KRSC) split into three bf16 planes for the pre-split x6 kernel (csrc/hip/conv_x6p.hip); recomputed
+        on every call because the optimizer has moved the weights (25 M parameters: ~0.1 ms per step in total)."""
+        if w.shape[3] % 32 or not ops.fp32_x6_active(ctx.cuda, w.dtype):
+            return None
+        buf = getattr(self, which)
+        if buf is None or buf.numel() != 3 * w.numel():
+            buf = torch.empty(3 * w.numel(), device=w.device, dtype=torch.bfloat16)
+            setattr(self, which, buf)
+        return ops.split3_planes(w, buf)
 
     def out_hw(self, h, w):
         return (ops.out_size(h, self.ksize[0], self.stride[0], self.padding[0]),
@@ -87,10 +100,14 @@ class Conv2d:
         bias = self.store.view(self.b) if self.b is not None else None
         w = self.store.cview(self.w)
         if self._as_gemm(x):      # whole-map 'valid' kernel = plain GEMM over the flattened (h, w, c) features
-            ops.conv_fprop(x.view(n, 1, 1, -1), w.view(w.shape[0], 1, 1, -1), out, (1, 1), (0, 0), bias=bias, relu=relu,
-                           stats=stats, stats_shift=stats_shift)
+            w = w.view(w.shape[0], 1, 1, -1)
+            ops.conv_fprop(x.view(n, 1, 1, -1), w, out, (1, 1), (0, 0), bias=bias, relu=relu,
+                           stats=stats, stats_shift=stats_shift, w3=self._planes(ctx, w, "_w3"))
         else:
-            ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats, stats_shift=stats_shift)
+            ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats, stats_shift=stats_shift,
+                           w3=self._planes(ctx, w, "_w3"))
+        if stats is not None:
+            self.last_stats_rows = ops.last_conv_stats_rows(ctx.cuda)
         return out
 
     def _as_gemm(self, x: torch.Tensor) -> bool:
@@ -153,14 +170,15 @@ class Conv2d:
             k, r, s, c = w.shape
             self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
         ops.transpose_krsc(w, self._wt)
+        wt3 = self._planes(ctx, self._wt, "_wt3")
         stride, padding = ((1, 1), (0, 0)) if gemm else (self.stride, self.padding)
         flat = (lambda t: t.view(t.shape[0], 1, 1, -1)) if gemm else (lambda t: t)
         if x.grad is None:
             dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
-            ops.conv_dgrad(dy, self._wt, flat(dx), stride, padding)
+            ops.conv_dgrad(dy, self._wt, flat(dx), stride, padding, wt3=wt3)
             x.grad = dx
         else:
-            ops.conv_dgrad(dy, self._wt, flat(x.grad), stride, padding, addend=flat(x.grad))
+            ops.conv_dgrad(dy, self._wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3)
 
     def __call__(self, ctx: Context, x: Act, relu=False, out=None) -> Act:
         y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
@@ -246,6 +264,8 @@ class ConvBNAct:
         m, cp = n * ho * wo, pad_to(conv.cout)
         slab = _stats_slab(ctx, m, cp, True) if ctx.training else None
         z = conv.forward_raw(ctx, x.data, stats=slab, stats_shift=bn.stat_shift(ctx))
+        if slab is not None:
+            slab = slab[: conv.last_stats_rows]       # the rows the chosen kernel / tile plan actually wrote
         a = bn.coeffs(ctx, slab, m)
         if out is None:
             out = ctx.empty((n, ho, wo, cp))

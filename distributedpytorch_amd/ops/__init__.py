@@ -48,7 +48,26 @@ pool_out_size = ref_ops.pool_out_size
 
 
 def stats_rows(m, cout, cuda, dtype=torch.float32):
-    return _hip().stats_rows(m, cout, dtype) if cuda else 1
+    """Upper bound on the rows of the BN-statistics slab a conv_fprop over m rows writes (one row per M-tile; the
+    smallest M-tile of any kernel variant is 64 rows).  The launch reports the rows it actually wrote:
+    last_conv_stats_rows()."""
+    return (m + 63) // 64 if cuda else 1
+
+
+def last_conv_stats_rows(cuda):
+    return _hip().last_stats_rows[0] if cuda else 1
+
+
+def split3_planes(w, out):
+    return _hip().split3_planes(w, out)
+
+
+def fp32_x6_active(cuda, dtype):
+    """Is the pre-split-filter fast path of the fp32 convolutions worth preparing (GPU, fp32, x6 arithmetic)?"""
+    if not cuda or dtype != torch.float32:
+        return False
+    from . import native
+    return native.get_fp32_mode() == "x6"
 
 
 def bn_slab_rows(m, cuda):

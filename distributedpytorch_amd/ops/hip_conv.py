@@ -32,7 +32,18 @@ def out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None):
+last_stats_rows = [0]       # rows of the stats slab the most recent conv_fprop wrote (depends on the kernel / tile plan)
+
+
+def split3_planes(w, out):
+    """fp32 tensor (numel % 32 == 0) -> three bf16 planes in 'x6 plane order' (csrc/hip/conv_x6p.hip): the B operand of the
+    pre-split fp32 convolution kernel.  out: bf16 buffer of 3 * w.numel() elements."""
+    assert w.dtype == torch.float32 and out.dtype == torch.bfloat16 and w.is_contiguous() and out.numel() >= 3 * w.numel()
+    native.hip_lib().dpa_split3_planes(VP(w.data_ptr()), VP(out.data_ptr()), ctypes.c_longlong(w.numel()), native.stream_ptr())
+    return out
+
+
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats: fp32 [rows, 2, Cout] slab written with per-block
     (sum, sumsq) of the stored outputs minus the per-channel `stats_shift` (0 if None); rows = stats_rows(M, Cout)."""
     lib = native.hip_lib()
@@ -44,6 +55,7 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     p.stats = native.ptr(stats)
     p.addend = native.ptr(addend)
     p.stats_shift = native.ptr(stats_shift)
+    p.wgt3, p.wgt3_plane = native.ptr(w3), w.numel()
     p.sN, p.sH, p.sW, p.sC = x.shape
     p.s_cs, p.s_co = _check_nhwc(x, "x"), 0
     p.dH, p.dW, p.dC = y.shape[1], y.shape[2], y.shape[3]
@@ -58,10 +70,11 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     rc = lib.dpa_conv_igemm(ctypes.byref(p), _DT[x.dtype], 0, native.stream_ptr())
     if rc:
         raise RuntimeError(f"dpa_conv_igemm(fprop) rejected geometry rc={rc}: x{tuple(x.shape)} w{tuple(w.shape)}")
+    last_stats_rows[0] = int(p.stats_rows_used)
     return y
 
 
-def conv_dgrad(dy, wt, dx, stride, pad, addend=None):
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None):
     """dx = conv_transpose(dy, w).  wt is the filter transposed to [Cin, kh, kw, Cout] (reduction-contiguous).
     addend (same geometry as dx) is added in the epilogue (gradient accumulation for fan-out)."""
     lib = native.hip_lib()
@@ -70,6 +83,7 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None):
     p = ConvParams()
     p.src, p.wgt, p.dst = VP(dy.data_ptr()), VP(wt.data_ptr()), VP(dx.data_ptr())
     p.bias, p.stats, p.addend, p.stats_shift = VP(0), VP(0), native.ptr(addend), VP(0)
+    p.wgt3, p.wgt3_plane = native.ptr(wt3), wt.numel()
     p.sN, p.sH, p.sW, p.sC = dy.shape
     p.s_cs, p.s_co = _check_nhwc(dy, "dy"), 0
     p.dH, p.dW, p.dC = dx.shape[1], dx.shape[2], dx.shape[3]

@@ -31,13 +31,13 @@ class FastDiv(ctypes.Structure):
 
 class ConvParams(ctypes.Structure):
     _fields_ = [
-        ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP), ("stats_shift", VP),
+        ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP), ("stats_shift", VP), ("wgt3", VP), ("wgt3_plane", I64),
         ("sN", I32), ("sH", I32), ("sW", I32), ("sC", I32), ("s_cs", I32), ("s_co", I32),
         ("dH", I32), ("dW", I32), ("dC", I32), ("d_cs", I32), ("d_co", I32),
         ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),
         ("M", I32), ("Kg", I32), ("relu", I32), ("no_uni", I32), ("m_off", I32), ("stats_row0", I32), ("splitK", I32), ("kt_per_split", I32), ("ws", VP), ("tilesM", I32), ("tilesN", I32),
         ("cls_h0", I32), ("cls_w0", I32), ("cls_nh", I32), ("cls_nw", I32), ("base_y", I32), ("base_x", I32),
-        ("tap_r0", I32), ("tap_s0", I32), ("nR", I32), ("nS", I32),
+        ("tap_r0", I32), ("tap_s0", I32), ("nR", I32), ("nS", I32), ("stats_rows_used", I32),
         ("fd_nW", FastDiv), ("fd_nH", FastDiv), ("fd_sC", FastDiv), ("fd_nS", FastDiv),
     ]
 

@@ -29,7 +29,7 @@ def stats_rows(m, cout):
     return 1
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None):
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None):
     out = F.conv2d(_nchw(x).float(), _nchw(w).float(), None if bias is None else bias.float()[: w.shape[0]],
                    stride=stride, padding=pad)
     out = _nhwc(out)
@@ -49,7 +49,7 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     return y
 
 
-def conv_dgrad(dy, wt, dx, stride, pad, addend=None):
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None):
     # wt: [Cin, kh, kw, Cout]  -> torch weight [Cout, Cin, kh, kw]
     w = wt.permute(3, 0, 1, 2).float()
     n, h, wd, c = dx.shape

@@ -128,36 +128,63 @@ def main():
     ap.add_argument("--n-test", type=int, default=10000)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--seed", type=int, default=1234, help="first seed (model init, split, shuffles, augmentation)")
+    ap.add_argument("--seeds", type=int, default=1, help="number of seeds: seed, seed+1, ... (the DATASET stays the one of --seed)")
+    ap.add_argument("--hard", action="store_true",
+                    help="the harder synthetic digits (per-sample stroke variation, overlapping classes): accuracies "
+                         "saturate below 100 %, so the comparison discriminates (VERDICT r1 #8)")
     ap.add_argument("--out", default="")
     ap.add_argument("--data", default="")
     a = ap.parse_args()
+    from distributedpytorch_amd.ops.native import set_fp32_mode
     path = a.data or tempfile.mkdtemp(prefix="dpa_mnist_")
     if not mnist.have_mnist(path) and not mnist.have_synthetic(path):
-        mnist.generate_synthetic_mnist(path, n_train=a.n_train, n_test=a.n_test, seed=a.seed)
-    res = {"config": vars(a), "data": "synthetic MNIST (data/mnist.py generator; real MNIST is not available offline)"}
-    print("engine fp32", flush=True)
-    res["engine_fp32"], sd0 = run_engine(path, torch.float32, a.epochs, a.batch, a.seed)
-    print("torch eager fp32 (reference restatement)", flush=True)
-    res["torch_fp32"] = run_torch(path, a.epochs, a.batch, a.seed, sd0)
-    print("engine fp32, x6 mode (fp32 products on the bf16 matrix pipe)", flush=True)
-    from distributedpytorch_amd.ops.native import set_fp32_mode
-    prev = set_fp32_mode("x6")
-    try:
-        res["engine_fp32_x6"], _ = run_engine(path, torch.float32, a.epochs, a.batch, a.seed, init_sd=sd0)
-    finally:
-        set_fp32_mode(prev)
-    print("engine bf16", flush=True)
-    res["engine_bf16"], _ = run_engine(path, torch.bfloat16, a.epochs, a.batch, a.seed, init_sd=sd0)
-    runs = ("torch_fp32", "engine_fp32", "engine_fp32_x6", "engine_bf16")
-    summary = {k: round(res[k]["test_acc"], 2) for k in runs}
-    res["summary_test_acc_percent"] = summary
-    res["summary_seconds"] = {k: round(res[k]["seconds"], 1) for k in runs}
-    print(json.dumps({"test_acc_percent": summary, "seconds": res["summary_seconds"]}), flush=True)
-    if a.out:
-        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
-        with open(a.out, "w") as fh:
-            json.dump(res, fh, indent=1)
+        t0 = time.time()
+        mnist.generate_synthetic_mnist(path, n_train=a.n_train, n_test=a.n_test, seed=a.seed, hard=a.hard)
+        print(f"generated the {'hard ' if a.hard else ''}synthetic digits in {time.time() - t0:.0f}s", flush=True)
+    runs = ("torch_fp32", "engine_fp32_exact", "engine_fp32_x6", "engine_bf16")
+    res = {"config": vars(a), "data": ("hard " if a.hard else "") + "synthetic MNIST (data/mnist.py generator; real MNIST is not "
+           "available offline: parity unpinned w.r.t. the real files)", "per_seed": []}
+
+    def dump():
+        if a.out:
+            os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+            with open(a.out, "w") as fh:
+                json.dump(res, fh, indent=1)
+
+    for seed in range(a.seed, a.seed + a.seeds):
+        one = {"seed": seed}
+        print(f"=== seed {seed}: engine fp32 (exact MFMA)", flush=True)
+        prev = set_fp32_mode("exact")
+        try:
+            one["engine_fp32_exact"], sd0 = run_engine(path, torch.float32, a.epochs, a.batch, seed)
+        finally:
+            set_fp32_mode(prev)
+        print("torch eager fp32 (reference restatement), same initial weights and batches", flush=True)
+        one["torch_fp32"] = run_torch(path, a.epochs, a.batch, seed, sd0)
+        print("engine fp32, x6 arithmetic (the default)", flush=True)
+        prev = set_fp32_mode("x6")
+        try:
+            one["engine_fp32_x6"], _ = run_engine(path, torch.float32, a.epochs, a.batch, seed, init_sd=sd0)
+        finally:
+            set_fp32_mode(prev)
+        print("engine bf16", flush=True)
+        one["engine_bf16"], _ = run_engine(path, torch.bfloat16, a.epochs, a.batch, seed, init_sd=sd0)
+        res["per_seed"].append(one)
+        print(json.dumps({"seed": seed, "test_acc_percent": {k: round(one[k]["test_acc"], 2) for k in runs}}), flush=True)
+        dump()
+    import statistics as st
+    summary = {}
+    for k in runs:
+        accs = [o[k]["test_acc"] for o in res["per_seed"]]
+        vals = [o[k]["history"][-1]["valid_acc"] * 100 for o in res["per_seed"]]
+        summary[k] = dict(test_acc_mean=round(st.mean(accs), 3), test_acc_sd=round(st.stdev(accs), 3) if len(accs) > 1 else None,
+                          test_acc_min=round(min(accs), 3), test_acc_max=round(max(accs), 3),
+                          final_valid_acc_mean=round(st.mean(vals), 3), per_seed_test_acc=[round(v, 2) for v in accs],
+                          seconds_mean=round(st.mean(o[k]["seconds"] for o in res["per_seed"]), 1))
+    res["summary"] = summary
+    print(json.dumps(summary), flush=True)
+    dump()
 
 
 if __name__ == "__main__":

@@ -15,8 +15,11 @@ dy = torch.randn(N, ho, ho, co, device="cuda").to(dt)
 dx = torch.empty_like(x)
 dw = torch.empty(co, k, k, ci, device="cuda")
 ws = torch.empty(H.wgrad_workspace_numel(co, k * k * ci), device="cuda")
+pre = os.environ.get("DPA_ONE_CONV_PRESPLIT", "0") == "1" and dt == torch.float32      # the pre-split x6 kernel (conv_x6p.hip)
+w3 = H.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16)) if pre else None
+wt3 = H.split3_planes(wt, torch.empty(3 * wt.numel(), device="cuda", dtype=torch.bfloat16)) if pre else None
 for _ in range(3):
-    if mode == "fprop": H.conv_fprop(x, w, y, (s, s), (p, p))
-    elif mode == "dgrad": H.conv_dgrad(dy, wt, dx, (s, s), (p, p))
+    if mode == "fprop": H.conv_fprop(x, w, y, (s, s), (p, p), w3=w3)
+    elif mode == "dgrad": H.conv_dgrad(dy, wt, dx, (s, s), (p, p), wt3=wt3)
     else: H.conv_wgrad(dy, x, dw, (k, k), (s, s), (p, p), workspace=ws)
 torch.cuda.synchronize()

@@ -120,3 +120,72 @@ def test_conv_splitk_skinny_gemm(dtype, fp32_mode):
     dx = torch.full((N, 1, 1, K), float("nan"), device="cuda", dtype=dtype)
     hip_conv.conv_dgrad(dy, wt, dx, (1, 1), (0, 0))
     torch.testing.assert_close(dx.float().view(N, K), dy.float().view(N, C) @ w.float().view(C, K), **tol)
+
+
+# (N, H, W, Cin, Cout, k, stride, pad): shapes routed to the pre-split x6 kernel (Cin % 32 == 0), with ragged tiles
+PRESPLIT_SHAPES = [
+    (4, 56, 56, 64, 64, 3, 1, 1),      # BN = 64 variant
+    (3, 28, 28, 128, 128, 3, 1, 1),    # BN = 128 variant, M = 2352 (18.4 tiles: ragged last tile)
+    (2, 28, 28, 64, 128, 3, 2, 1),     # stride 2: dgrad parity classes
+    (2, 14, 14, 256, 1024, 1, 1, 0),   # 1x1 expand
+    (5, 14, 14, 1024, 256, 1, 1, 0),   # 1x1 reduce, long reduction
+    (2, 17, 13, 96, 72, 3, 1, 1),      # Cout neither a multiple of 64 nor of 128, odd spatial sizes
+    (2, 28, 28, 256, 512, 1, 2, 0),    # downsample: 1x1 stride 2 (three of four dgrad classes have no taps)
+    (130, 1, 1, 512, 160, 1, 1, 0),    # linear-shaped
+]
+
+
+@pytest.mark.parametrize("shape", PRESPLIT_SHAPES)
+def test_conv_presplit_x6_kernel(shape):
+    """csrc/hip/conv_x6p.hip (fp32 through the bf16 matrix pipe with the filter pre-split into three bf16 planes, waves
+    stacked along M) against the fp32 PyTorch reference: fprop with the whole fused epilogue (bias, shifted BN statistics,
+    addend, ReLU, channel-sliced destination) and dgrad (fresh and accumulating in place)."""
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    w = torch.randn(K, k, k, C, device="cuda", generator=g) * (k * k * C) ** -0.5
+    b = torch.randn(K, device="cuda", generator=g)
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    M = N * Ho * Wo
+    prev = set_fp32_mode("x6")
+    try:
+        w3 = hip_conv.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
+        # plain
+        y = torch.full((N, Ho, Wo, K), float("nan"), device="cuda")
+        stats = torch.full(((M + 63) // 64, 2, K), float("nan"), device="cuda")
+        shift = torch.randn(K, device="cuda", generator=g) * 0.1
+        hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd), bias=b, stats=stats, stats_shift=shift, w3=w3)
+        rows = hip_conv.last_stats_rows[0]
+        assert rows == (M + 127) // 128                 # one slab row per 128-row tile: the pre-split kernel ran
+        yr = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=s, padding=pd).permute(0, 2, 3, 1)
+        rtol, atol = _tol(torch.float32, k * k * C)
+        torch.testing.assert_close(y, yr, rtol=rtol, atol=atol * 10)
+        st = stats[:rows].sum(0)
+        yc = (y - shift).reshape(-1, K)
+        torch.testing.assert_close(st[0], yc.sum(0), rtol=1e-3, atol=1e-2)
+        torch.testing.assert_close(st[1], (yc * yc).sum(0), rtol=1e-3, atol=1e-2)
+        # fused addend + ReLU into a channel slice of a wider buffer
+        buf = torch.zeros(N, Ho, Wo, K + 16, device="cuda")
+        add = torch.randn(N, Ho, Wo, K + 16, device="cuda", generator=g)
+        hip_conv.conv_fprop(x, w, buf[..., 8:8 + K], (s, s), (pd, pd), bias=b, relu=True, addend=add[..., 8:8 + K], w3=w3)
+        torch.testing.assert_close(buf[..., 8:8 + K], (yr + add[..., 8:8 + K]).clamp_min(0), rtol=rtol, atol=atol * 10)
+        assert buf[..., :8].abs().max() == 0 and buf[..., 8 + K:].abs().max() == 0
+        # dgrad: fresh, then accumulating in place
+        if K % 32 == 0:
+            dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g)
+            wt = w.permute(3, 1, 2, 0).contiguous()
+            wt3 = hip_conv.split3_planes(wt, torch.empty(3 * wt.numel(), device="cuda", dtype=torch.bfloat16))
+            ref_dx = torch.nn.grad.conv2d_input((N, C, H, W), w.permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2), stride=s,
+                                                padding=pd).permute(0, 2, 3, 1)
+            dx = torch.full((N, H, W, C), float("nan"), device="cuda")
+            hip_conv.conv_dgrad(dy, wt, dx, (s, s), (pd, pd), wt3=wt3)
+            rt, at = _tol(torch.float32, k * k * K)
+            torch.testing.assert_close(dx, ref_dx, rtol=rt, atol=at * 10)
+            acc = torch.randn(N, H, W, C, device="cuda", generator=g)
+            acc0 = acc.clone()
+            hip_conv.conv_dgrad(dy, wt, acc, (s, s), (pd, pd), addend=acc, wt3=wt3)
+            torch.testing.assert_close(acc, acc0 + ref_dx, rtol=rt, atol=at * 10)
+    finally:
+        set_fp32_mode(prev)

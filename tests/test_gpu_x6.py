@@ -144,10 +144,33 @@ X6_VARIANTS = [
 ]
 
 
+def _planes(w):
+    """The filter as three bf16 planes: the B operand of the pre-split kernel (csrc/hip/conv_x6p.hip)."""
+    from distributedpytorch_amd.ops import hip_conv
+    if w.shape[3] % 32:
+        return None
+    return hip_conv.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
+
+
+def test_split3_planes_are_exact_and_in_plane_order():
+    """p0 + p1 + p2 == w bit for bit (three bf16 parts cover the 24-bit significand), stored in 'x6 plane order'."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    w = _wide((64, 3, 3, 96), g, -30, 30)
+    pl = _planes(w).view(3, -1, 4, 8).float()                     # [plane][group of 32][q][j]
+    total = (pl[0].double() + pl[1].double() + pl[2].double())
+    wg = w.view(-1, 32).double()
+    k = torch.tensor([[(4 * q + j) if j < 4 else (16 + 4 * q + j - 4) for j in range(8)] for q in range(4)], device="cuda")
+    assert torch.equal(total, wg[:, k])                            # exact: nothing of the fp32 value is lost
+    assert torch.equal(pl[0], wg[:, k].float().bfloat16().float())  # plane 0 = round-to-nearest bf16 of the value
+
+
+@pytest.mark.parametrize("presplit", [False, True])
 @pytest.mark.parametrize("name,shape", X6_VARIANTS)
-def test_x6_per_element_bound_fprop_dgrad_wgrad(name, shape):
+def test_x6_per_element_bound_fprop_dgrad_wgrad(name, shape, presplit):
     from distributedpytorch_amd.ops import hip_conv
     from distributedpytorch_amd.ops.native import set_fp32_mode
+    if presplit and shape[3] % 32:
+        pytest.skip("the pre-split kernel needs Cin % 32 == 0")
     N, H, W, C, K, k, s, pd = shape
     g = torch.Generator(device="cuda").manual_seed(321)
     x = _wide((N, H, W, C), g, -20, 20)
@@ -168,9 +191,11 @@ def test_x6_per_element_bound_fprop_dgrad_wgrad(name, shape):
         for mode in ("exact", "x6"):
             set_fp32_mode(mode)
             y = torch.empty(N, Ho, Wo, K, device="cuda")
-            hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd))
+            wt = w.permute(3, 1, 2, 0).contiguous()
+            use = presplit and mode == "x6"
+            hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd), w3=_planes(w) if use else None)
             dx = torch.empty(N, H, W, C, device="cuda")
-            hip_conv.conv_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), dx, (s, s), (pd, pd))
+            hip_conv.conv_dgrad(dy, wt, dx, (s, s), (pd, pd), wt3=_planes(wt) if use and K % 32 == 0 else None)
             dw = torch.empty(K, k, k, C, device="cuda")
             ws = torch.empty(hip_conv.wgrad_workspace_numel(K, k * k * C), device="cuda")
             hip_conv.conv_wgrad(dy, x, dw, (k, k), (s, s), (pd, pd), workspace=ws)
