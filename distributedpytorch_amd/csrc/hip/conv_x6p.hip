@@ -17,10 +17,12 @@
 // Only the uniform-tap address path (Cin % 32 == 0: every layer of the zoo but the stems) - other shapes keep the
 // general kernel.
 //
-// "x6 plane order": inside every group of 32 consecutive reduction elements the planes store element
-// k = (j < 4 ? 4 q + j : 16 + 4 q + j - 4) at position 8 q + j (q = 0..3, j = 0..7), which is the order in which a lane
-// of the A fragment holds its 8 fp32 values (chunks q and 4 + q of the 128-byte row), so one ds_read_b128 of a plane is
-// one MFMA operand.
+// Planes are in natural element order.  A lane of an A fragment holds 8 consecutive reduction elements (two adjacent
+// 16-byte chunks of the fp32 row), so one ds_read_b128 of a plane (8 bf16) is the matching MFMA operand.
+//
+// MFMA shape: v_mfma_f32_16x16x32_bf16, 2 x TN tiles per wave.  (A v_mfma_f32_32x32x16_bf16 variant - 1 x TN/2 tiles,
+// two k-steps per K-tile, half as many matrix instructions - measured 7 % SLOWER over the ResNet-50 layers:
+// profiles/r2_x6p_variants.txt.  So did 8 waves per block and one block per CU.)
 #include "conv_common.h"
 
 __device__ uint4 dpa_zero_chunk_x6p[4];
@@ -34,13 +36,12 @@ __device__ __forceinline__ void split3_frag(const uint4& lo, const uint4& hi, ui
   for (int part = 0; part < 3; ++part) pl[part] = make_uint4(o[0][part], o[1][part], o[2][part], o[3][part]);
 }
 
-// n fp32 values (n % 32 == 0) -> three bf16 planes of n values each, in x6 plane order.  One thread per 8 outputs.
+// n fp32 values (n % 32 == 0) -> three bf16 planes of n values each.  One thread per 8 values.
 __global__ void __launch_bounds__(256) split3_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long long n) {
   const long long nchunks = n >> 3;
   for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
-    const long long g = c >> 2; const int q = (int)(c & 3);          // group of 32, output chunk q
-    const float4 lo = *reinterpret_cast<const float4*>(w + g * 32 + 4 * q);
-    const float4 hi = *reinterpret_cast<const float4*>(w + g * 32 + 16 + 4 * q);
+    const float4 lo = *reinterpret_cast<const float4*>(w + c * 8);
+    const float4 hi = *reinterpret_cast<const float4*>(w + c * 8 + 4);
     uint4 pl[3];
     split3_frag(make_uint4(__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)),
                 make_uint4(__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)), pl);
@@ -56,9 +57,9 @@ DPA_API int dpa_split3_planes(const float* w, void* out, long long n, hipStream_
 
 // NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
 // 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
-template <int TN, bool DGRAD, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2)) conv_x6p_kernel(const ConvParams p) {
-  constexpr int TM = 2, BM = 32 * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
+template <int TN, bool DGRAD, int NW, int MF>
+__global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p) {
+  constexpr int BM = 32 * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
   constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
   constexpr int STAGE_BYTES = A_BYTES + 3 * BP_BYTES;
   constexpr int RPP = NT / 8;                      // rows staged per pass (8 threads per 128-byte row)
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2)) conv_x6p_kernel(co
       a_mask[i] = mk;
     }
   }
-  // ---- B operand: piece q = wave + 4 i of the K-tile: plane q / TN, rows 16 (q % TN) .. + 15; lane -> row lane >> 2,
+  // ---- B operand: piece q = wave + NW i of the K-tile: plane q / TN, rows 16 (q % TN) .. + 15; lane -> row lane >> 2,
   //      slot lane & 3, which holds logical chunk slot ^ ((-(row >> 2)) & 3) -----------------------------------------------
   long long b_off[B_PIECES];
   int b_lds[B_PIECES];
@@ -143,89 +144,17 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2)) conv_x6p_kernel(co
         __builtin_amdgcn_global_load_lds((gbl_void*)(wgt3 + b_off[i] + woff), (lds_void*)(stage + b_lds[i]), 16, 0, 0);
   };
 
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int nkt = (p.Kg + BKE - 1) / BKE;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int b_frag = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);     // + plane * BP_BYTES + j * 1024
-  constexpr int JH = TN > 4 ? 4 : TN;                                // filter fragments held in registers at a time
-
-  if (nkt > 0) issue_tile(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const char* tA = smem + (kt & 1) * STAGE_BYTES;
-    const char* tB = tA + A_BYTES;
-    uint4 fa[2][TM];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * 32 + i * 16 + fr, ks * 4 + fq));
-    uint4 bp[JH][3];
-#pragma unroll
-    for (int j = 0; j < JH; ++j)
-#pragma unroll
-      for (int part = 0; part < 3; ++part)
-        bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
-    if constexpr (TN <= 4) { if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1); }
-    uint4 ap[TM][3];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
-    if constexpr (TN > 4) {
-      // second half of the filter fragments: read them, THEN issue the next tile's DMA (the compiler puts
-      // s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA issue), then the other 48 MFMAs
-#pragma unroll
-      for (int j = 0; j < JH; ++j)
-#pragma unroll
-        for (int part = 0; part < 3; ++part)
-          bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + (JH + j) * 1024 + b_frag);
-      if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-          for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][JH + j]);
-    }
-  }
-  __syncthreads();
-
-  // ---------------------------------------- epilogue (as conv_igemm.hip, for the 4 x 1 wave arrangement) ------------
-  // acc[i][j][e] = D[row = wave*32 + i*16 + fq*4 + e][col = j*16 + fr]
   float* __restrict__ dst = reinterpret_cast<float*>(p.dst);
   const float* __restrict__ addend = reinterpret_cast<const float*>(p.addend);
   constexpr int PITCH = BN + 4;
   float* stage = reinterpret_cast<float*>(smem) + wave * (16 * PITCH);
   float* red = reinterpret_cast<float*>(smem) + NW * 16 * PITCH;      // [NW waves][2][BN]
-  float csum[TN], csq[TN], bj[TN], cj[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + j * 16 + fr;
-    csum[j] = 0.f; csq[j] = 0.f;
-    bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
-    cj[j] = (p.stats && p.stats_shift && col < p.dC) ? p.stats_shift[col] : 0.f;
-  }
   constexpr int LPR = BN / 4;                  // lanes per output row (16-byte chunks)
   constexpr int RPI = 64 / LPR;                // rows per store instruction
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) stage[(fq * 4 + e) * PITCH + j * 16 + fr] = acc[i][j][e] + bj[j];
-    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
+
+  // 16 staged rows (block rows m0 + wave*32 + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map
+  auto store_rows = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < 16; rr += RPI) {
       const int r = rr + lane / LPR;
@@ -251,43 +180,126 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 ? 2 : 2)) conv_x6p_kernel(co
         *reinterpret_cast<float4*>(dst + off) = v;
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (p.stats) {
-      const bool interior = m0 + BM <= p.M;      // block-uniform
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[i][j][e] + bj[j] - cj[j];
-          if (!interior && m0 + wave * 32 + i * 16 + fq * 4 + e >= p.M) v = 0.f;
-          csum[j] += v; csq[j] += v * v;
-        }
-    }
-  }
-  if (p.stats) {
-    __syncthreads();                             // the staging region is reused below (block-wide)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = csum[j], q = csq[j];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (fq == 0) {
-        red[(wave * 2 + 0) * BN + j * 16 + fr] = s;
-        red[(wave * 2 + 1) * BN + j * 16 + fr] = q;
-      }
-    }
+  };
+  // block-wide: per-wave column sums in red[] -> one slab row per M-tile, waves added in fixed order (reproducible)
+  auto write_stats = [&]() __attribute__((always_inline)) {
     __syncthreads();
     for (int c = tid; c < 2 * BN; c += NT) {
       const int which = c / BN, col = c - which * BN;
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * BN + col];     // fixed order: reproducible
+      for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * BN + col];
       if (n0 + col < p.dC) p.stats[((size_t)(p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
+    }
+  };
+  const bool interior = m0 + BM <= p.M;          // block-uniform
+
+  {
+    constexpr int TM = 2;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b_frag = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);     // + plane * BP_BYTES + j * 1024
+    constexpr int JH = TN > 4 ? 4 : TN;                                // filter fragments held in registers at a time
+
+    if (nkt > 0) issue_tile(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const char* tA = smem + (kt & 1) * STAGE_BYTES;
+      const char* tB = tA + A_BYTES;
+      uint4 fa[2][TM];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * 32 + i * 16 + fr, 2 * fq + ks));
+      uint4 bp[JH][3];
+#pragma unroll
+      for (int j = 0; j < JH; ++j)
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+          bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
+      if constexpr (TN <= 4) { if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1); }
+      uint4 ap[TM][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+      if constexpr (TN > 4) {
+        // second half of the filter fragments: read them, THEN issue the next tile's DMA (the compiler puts
+        // s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA issue), then the other 48 MFMAs
+#pragma unroll
+        for (int j = 0; j < JH; ++j)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + (JH + j) * 1024 + b_frag);
+        if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][JH + j]);
+      }
+    }
+    __syncthreads();
+
+    // ---- epilogue: acc[i][j][e] = D[row = wave*32 + i*16 + fq*4 + e][col = j*16 + fr] ---------------------------------
+    float csum[TN], csq[TN], bj[TN], cj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + j * 16 + fr;
+      csum[j] = 0.f; csq[j] = 0.f;
+      bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
+      cj[j] = (p.stats && p.stats_shift && col < p.dC) ? p.stats_shift[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stage[(fq * 4 + e) * PITCH + j * 16 + fr] = acc[i][j][e] + bj[j];
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      store_rows(i);
+      __builtin_amdgcn_wave_barrier();
+      if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][e] + bj[j] - cj[j];
+            if (!interior && m0 + wave * 32 + i * 16 + fq * 4 + e >= p.M) v = 0.f;
+            csum[j] += v; csq[j] += v * v;
+          }
+      }
+    }
+    if (p.stats) {
+      __syncthreads();                             // the staging region is reused below (block-wide)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = csum[j], q = csq[j];
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        if (fq == 0) {
+          red[(wave * 2 + 0) * BN + j * 16 + fr] = s;
+          red[(wave * 2 + 1) * BN + j * 16 + fr] = q;
+        }
+      }
+      write_stats();
     }
   }
 }
 
-template <int TN, int NW>
+template <int TN, int NW, int MF>
 static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   constexpr int BN = TN * 16, BM = 32 * NW;
   p.tilesM = (p.M - p.m_off + BM - 1) / BM;
@@ -297,8 +309,8 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
-  if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW>), grid, block, lds, s, p);
-  else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW>), grid, block, lds, s, p);
+  if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF>), grid, block, lds, s, p);
+  else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
 }
 
 // Can this (sub-)problem take the pre-split kernel?  (called by conv_igemm.hip's launch_tiles for fp32 in x6 mode)
@@ -308,17 +320,10 @@ bool dpa_x6p_eligible(const ConvParams& p) {
   const int ntaps = p.nR * p.nS;
   return enabled && p.wgt3 && (p.sC % 32 == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni && p.Kg >= 32 * min_kt && p.dC >= 16;
 }
-// Rows per M-tile the launcher will use for this problem (one stats-slab row per M-tile).
-static int x6p_waves(const ConvParams& p) {
-  static const int nw_env = [] { const char* e = getenv("DPA_X6P_WAVES"); return e ? atoi(e) : 0; }();
-  if (nw_env == 4 || nw_env == 8) return nw_env;
-  return 4;
-}
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   p.m_off = 0; p.stats_row0 = 0;
-  const int nw = x6p_waves(p);
-  if (p.dC <= 64) { if (nw == 8) x6p_launch<4, 8>(p, dgrad, s); else x6p_launch<4, 4>(p, dgrad, s); }
-  else            { if (nw == 8) x6p_launch<8, 8>(p, dgrad, s); else x6p_launch<8, 4>(p, dgrad, s); }
+  if (p.dC <= 64) x6p_launch<4, 4, 16>(p, dgrad, s);
+  else            x6p_launch<8, 4, 16>(p, dgrad, s);
   return p.tilesM;
 }

@@ -36,7 +36,7 @@ last_stats_rows = [0]       # rows of the stats slab the most recent conv_fprop 
 
 
 def split3_planes(w, out):
-    """fp32 tensor (numel % 32 == 0) -> three bf16 planes in 'x6 plane order' (csrc/hip/conv_x6p.hip): the B operand of the
+    """fp32 tensor (numel % 32 == 0) -> three bf16 planes in element order (csrc/hip/conv_x6p.hip): the B operand of the
     pre-split fp32 convolution kernel.  out: bf16 buffer of 3 * w.numel() elements."""
     assert w.dtype == torch.float32 and out.dtype == torch.bfloat16 and w.is_contiguous() and out.numel() >= 3 * w.numel()
     native.hip_lib().dpa_split3_planes(VP(w.data_ptr()), VP(out.data_ptr()), ctypes.c_longlong(w.numel()), native.stream_ptr())

@@ -153,15 +153,13 @@ def _planes(w):
 
 
 def test_split3_planes_are_exact_and_in_plane_order():
-    """p0 + p1 + p2 == w bit for bit (three bf16 parts cover the 24-bit significand), stored in 'x6 plane order'."""
+    """p0 + p1 + p2 == w bit for bit (three bf16 parts cover the 24-bit significand); planes in element order."""
     g = torch.Generator(device="cuda").manual_seed(8)
     w = _wide((64, 3, 3, 96), g, -30, 30)
-    pl = _planes(w).view(3, -1, 4, 8).float()                     # [plane][group of 32][q][j]
+    pl = _planes(w).view(3, -1).float()
     total = (pl[0].double() + pl[1].double() + pl[2].double())
-    wg = w.view(-1, 32).double()
-    k = torch.tensor([[(4 * q + j) if j < 4 else (16 + 4 * q + j - 4) for j in range(8)] for q in range(4)], device="cuda")
-    assert torch.equal(total, wg[:, k])                            # exact: nothing of the fp32 value is lost
-    assert torch.equal(pl[0], wg[:, k].float().bfloat16().float())  # plane 0 = round-to-nearest bf16 of the value
+    assert torch.equal(total, w.view(-1).double())                 # exact: nothing of the fp32 value is lost
+    assert torch.equal(pl[0], w.view(-1).bfloat16().float())       # plane 0 = round-to-nearest bf16 of the value
 
 
 @pytest.mark.parametrize("presplit", [False, True])
