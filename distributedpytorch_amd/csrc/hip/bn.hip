@@ -368,6 +368,16 @@ DPA_API int dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, cons
                      mean, invstd, gamma, 1.0f / (float)M, coef);
   return dpa_launch_rc();
 }
+// The second half of dpa_bn_bwd_reduce alone: the per-tile partial sums were written by a dgrad epilogue
+// (ConvParams::bnr_slab, conv_common.h) - no pass over dy / y / x here.
+DPA_API int dpa_bn_bwd_from_slab(const float* slab, int rows, const float* mean, const float* invstd, const float* gamma,
+                                  long long M, int C, float* scratch, float* dgamma, float* dbeta, float* sums, float* coef,
+                                  int accumulate, hipStream_t s) {
+  const float* sl = shrink_slab(slab, &rows, C, scratch, s);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
+                     mean, invstd, gamma, 1.0f / (float)M, coef);
+  return dpa_launch_rc();
+}
 DPA_API int dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
                            long long M, int C, int dtype, hipStream_t s, const float* mscale, const float* mshift) {
   int nb; const int rpb = ew_rows_per_block(M, &nb);

@@ -37,9 +37,23 @@ struct ConvParams {
   const void* addend; // optional tensor with dst geometry added in the epilogue (dgrad accumulation) or null
   const float* stats_shift; // [dC] or null: the slab holds sum(v - c), sum((v - c)^2) about this per-channel shift c
                             // (shifted-data variance: no cancellation when |mean| >> std, see bn_finalize_kernel)
-  const void* wgt3;  // fp32 x6 fast path: the filter pre-split into three bf16 planes [3][dC][R][S][sC] in "x6 plane
-                     // order" (split3_planes_kernel), or null
+  const void* wgt3;  // fp32 x6 fast path: the filter pre-split into three bf16 planes [3][dC][R][S][sC]
+                     // (split3_planes_kernel), or null
   long long wgt3_plane;  // elements per plane
+  // dgrad only: BatchNorm-backward reduction fused into the epilogue.  dst is the gradient w.r.t. the OUTPUT of a
+  // BatchNorm(+ReLU) whose input was bnr_x: the epilogue applies the ReLU mask to the value it stores (from bnr_y > 0,
+  // or from bnr_mscale * x + bnr_mshift > 0, or none) and writes per-M-tile partial sums of dz and dz * xhat into
+  // bnr_slab [rows][2][dC] - the memory pass bn_bwd_reduce_kernel would otherwise make over dy, y and x.
+  const void* bnr_x;         // BN input, same pixels as dst, channel stride bnr_cs; null = no fusion
+  const void* bnr_y;         // BN(+residual)+ReLU output for the mask, channel stride bnr_y_cs; or null
+  const float* bnr_mean;     // [dC]
+  const float* bnr_invstd;   // [dC]
+  const float* bnr_mscale;   // [dC] or null
+  const float* bnr_mshift;   // [dC] or null
+  float* bnr_slab;
+  int bnr_cs, bnr_y_cs;
+  int bnr_row0;              // first slab row of this parity class (host)
+  int bnr_pad;
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;
@@ -108,6 +122,52 @@ __device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) 
 // order of the six partial products: small terms first
 __device__ constexpr int kX6A[6] = {1, 2, 0, 1, 0, 0};
 __device__ constexpr int kX6B[6] = {1, 0, 2, 0, 1, 0};
+
+// ---- fused BatchNorm-backward reduction (dgrad epilogues of conv_igemm.hip and conv_x6p.hip) --------------------------
+// One lane owns VEC consecutive channels of a few rows of the tile.
+template <typename T, int VEC>
+struct BnReduceLane {
+  float s[VEC], q[VEC], mu[VEC], is[VEC], msc[VEC], msh[VEC];
+  __device__ __forceinline__ void init(const ConvParams& p, int col) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const bool ok = col + e < p.dC;
+      s[e] = 0.f; q[e] = 0.f;
+      mu[e] = ok ? p.bnr_mean[col + e] : 0.f; is[e] = ok ? p.bnr_invstd[col + e] : 0.f;
+      msc[e] = (ok && p.bnr_mscale) ? p.bnr_mscale[col + e] : 0.f;
+      msh[e] = (ok && p.bnr_mscale) ? p.bnr_mshift[col + e] : 1.f;
+    }
+  }
+  // the same with the BatchNorm input x (and output y) already in registers
+  __device__ __forceinline__ void visit_loaded(bool have_y, const float (&x)[VEC], const float (&y)[VEC], float (&v)[VEC]) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const bool keep = have_y ? (y[e] > 0.f) : (x[e] * msc[e] + msh[e] > 0.f);      // (no mask: 0 * x + 1 > 0)
+      float d = keep ? v[e] : 0.f;
+      v[e] = d;
+      if (sizeof(T) == 2) d = bf2f(f2bf(d));
+      s[e] += d; q[e] += d * (x[e] - mu[e]) * is[e];
+    }
+  }
+  // v: the gradient values about to be stored for (pixel, col .. col + VEC); masked in place, sums updated
+  __device__ __forceinline__ void visit(const ConvParams& p, size_t pixel, int col, float (&v)[VEC]) {
+    Vec16<T> xv; xv.load(reinterpret_cast<const T*>(p.bnr_x) + pixel * (size_t)p.bnr_cs + col);
+    if (p.bnr_y) {
+      Vec16<T> yv; yv.load(reinterpret_cast<const T*>(p.bnr_y) + pixel * (size_t)p.bnr_y_cs + col);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) if (!(yv.get(e) > 0.f)) v[e] = 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) if (!(xv.get(e) * msc[e] + msh[e] > 0.f)) v[e] = 0.f;      // (no mask: 0 * x + 1 > 0)
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float d = v[e];
+      if (sizeof(T) == 2) d = bf2f(f2bf(d));     // sums of the values as stored
+      s[e] += d; q[e] += d * (xv.get(e) - mu[e]) * is[e];
+    }
+  }
+};
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 

@@ -342,6 +342,8 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
   }
   constexpr int LPR = WCOLS / VEC;             // lanes per output row (16-B chunks per row)
   constexpr int RPI = 64 / LPR;                // rows per store instruction
+  BnReduceLane<T, VEC> bnr;                    // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
+  if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + wn * WCOLS + (lane % LPR) * VEC); }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     // wave-private staging region: no block barrier needed between iterations, only LDS ordering
@@ -385,6 +387,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
 #pragma unroll
           for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        if constexpr (DGRAD) { if (p.bnr_x) bnr.visit(p, pixel, col, v); }
         Vec16<T> ov;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) ov.set(e, v[e]);
@@ -437,6 +440,30 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
 #pragma unroll
       for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
       if (n0 + col < p.dC) p.stats[((size_t)(p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
+    }
+  }
+  if constexpr (DGRAD) {
+    if (p.bnr_x) {       // lanes that share columns (lane % LPR) -> one value per wave, waves added in fixed order
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float s = bnr.s[e], q = bnr.q[e];
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lane < LPR) {
+          red[(wm * 2 + 0) * BN + wn * WCOLS + lane * VEC + e] = s;
+          red[(wm * 2 + 1) * BN + wn * WCOLS + lane * VEC + e] = q;
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < 2 * BN; c += 256) {
+        const int which = c / BN, col = c - which * BN;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
+        if (n0 + col < p.dC)
+          p.bnr_slab[((size_t)(p.bnr_row0 + p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
+      }
     }
   }
 }
@@ -535,6 +562,7 @@ static int x6_reg() {       // x6 also for the register-staged (short reduction)
 
 // rows of the stats slab written by the launches of the current dpa_conv_igemm call (reported back in ConvParams)
 static thread_local int g_stats_rows = 0;
+static thread_local int g_class_rows = 0;       // dgrad: rows summed over the parity classes
 bool dpa_x6p_eligible(const ConvParams& p);                       // conv_x6p.hip
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s);
 
@@ -568,7 +596,7 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   // statistics have to be rebuilt from the output afterwards only in bf16 (in fp32 that extra pass eats the gain).
   const bool linear_like = p.M <= 256 && ntiles * 2 <= 256 && nkt >= 32;
   const bool deep_conv = p.Kg >= 4096 && ntiles * 2 <= slots && (!p.stats || sizeof(T) == 2);
-  if (allow_split && p.sh == 1 && p.sw == 1 && p.m_off == 0 && (linear_like || deep_conv) &&
+  if (allow_split && !p.bnr_x && p.sh == 1 && p.sw == 1 && p.m_off == 0 && (linear_like || deep_conv) &&
       (long long)p.Kg * p.dC >= (1 << 20)) {      // enough weight traffic to pay for the extra launches
     int want = slots / ntiles;
     if (want > nkt / 8) want = nkt / 8;
@@ -743,16 +771,24 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
       q.Kg = q.nR * q.nS * p.sC;          // 0 taps: the kernel only runs its epilogue (zeros + addend)
       // ... and when the addend IS the destination (in-place accumulation into an existing gradient) a class without
       // taps leaves its pixels unchanged: nothing to launch (3 of the 4 classes of a 1x1 stride-2 downsample conv)
-      if (q.Kg == 0 && p.addend == p.dst) continue;
+      if (q.Kg == 0 && p.addend == p.dst) {
+        if (p.bnr_x) return 3;              // (the fused BN reduction has to visit every pixel; the caller checks R >= sh)
+        continue;
+      }
+      const int row_base = g_class_rows;    // slab rows of the classes launched so far (fused BN-backward reduction)
+      q.bnr_row0 = row_base;
+      g_stats_rows = 0;
       launch_tiles<T>(q, 1, s);
+      g_class_rows = row_base + g_stats_rows;
     }
+  g_stats_rows = g_class_rows;
   return 0;
 }
 
 // dtype: 0 = fp32, 1 = bf16.  Returns 0 on success, non-zero for an unsupported geometry.
 DPA_API int dpa_conv_igemm(ConvParams* p, int dtype, int dgrad, hipStream_t s) {
   ConvParams q = *p;
-  g_stats_rows = 0;
+  g_stats_rows = 0; g_class_rows = 0;
   const int rc = dtype == 1 ? launch_conv<bf16_t>(q, dgrad, s) : launch_conv<float>(q, dgrad, s);
   p->stats_rows_used = g_stats_rows;
   if (rc) return rc;                       // 1, 2: unsupported geometry (nothing was launched)

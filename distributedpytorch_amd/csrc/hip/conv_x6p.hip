@@ -153,43 +153,70 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
   constexpr int LPR = BN / 4;                  // lanes per output row (16-byte chunks)
   constexpr int RPI = 64 / LPR;                // rows per store instruction
 
-  // 16 staged rows (block rows m0 + wave*32 + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map
+  BnReduceLane<float, 4> bnr;                  // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
+  if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + (lane % LPR) * 4); }
+  // 16 staged rows (block rows m0 + wave*32 + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map, fused BN reduce.
+  // Two phases so that every global read of the 16 rows (addend, and for the fused BatchNorm reduction x and y) is in
+  // flight before the first one is consumed: issued one row group at a time, their latency was exposed 16 / RPI times
+  // per wave and the fused reduction cost more than the kernel it replaced.
   auto store_rows = [&](int i) __attribute__((always_inline)) {
+    constexpr int NG = 16 / RPI;
+    const int cc = (lane % LPR) * 4;
+    const int col = n0 + cc;
+    size_t off[NG], pix[NG];
+    bool ok[NG];
+    float4 av[NG], xv[NG], yv[NG];
+    const bool fuse = DGRAD && p.bnr_x != nullptr;
+    const float* __restrict__ bx = reinterpret_cast<const float*>(p.bnr_x);
+    const float* __restrict__ by = reinterpret_cast<const float*>(p.bnr_y);
 #pragma unroll
-    for (int rr = 0; rr < 16; rr += RPI) {
-      const int r = rr + lane / LPR;
-      const int cc = (lane % LPR) * 4;
-      const int m = m0 + wave * 32 + i * 16 + r;
-      const int col = n0 + cc;
+    for (int g = 0; g < NG; ++g) {
+      const int m = m0 + wave * 32 + i * 16 + g * RPI + lane / LPR;
+      ok[g] = m < p.M && col < p.dC;
+      size_t pixel = ok[g] ? (size_t)m : 0;
+      if (DGRAD && (p.sh != 1 || p.sw != 1) && ok[g]) {      // class row -> (img, hi, wi) of the full gradient tensor
+        const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+        const int jx = m - (int)t1 * p.cls_nw;
+        const uint32_t img = fd_div(t1, p.fd_nH);
+        const int iy = (int)t1 - (int)img * p.cls_nh;
+        pixel = ((size_t)img * p.dH + (size_t)(p.cls_h0 + p.sh * iy)) * p.dW + (size_t)(p.cls_w0 + p.sw * jx);
+      }
+      const int c_ok = ok[g] ? col : 0;
+      pix[g] = pixel;
+      off[g] = pixel * (size_t)p.d_cs + (size_t)(p.d_co + c_ok);
+      if (addend) av[g] = *reinterpret_cast<const float4*>(addend + off[g]);
+      if (fuse) {
+        xv[g] = *reinterpret_cast<const float4*>(bx + pixel * (size_t)p.bnr_cs + c_ok);
+        if (by) yv[g] = *reinterpret_cast<const float4*>(by + pixel * (size_t)p.bnr_y_cs + c_ok);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int r = g * RPI + lane / LPR;
       float4 v = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc]);
-      if (m < p.M && col < p.dC) {
-        size_t pixel = (size_t)m;
-        if (DGRAD && (p.sh != 1 || p.sw != 1)) {      // class row -> (img, hi, wi) of the full gradient tensor
-          const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
-          const int jx = m - (int)t1 * p.cls_nw;
-          const uint32_t img = fd_div(t1, p.fd_nH);
-          const int iy = (int)t1 - (int)img * p.cls_nh;
-          pixel = ((size_t)img * p.dH + (size_t)(p.cls_h0 + p.sh * iy)) * p.dW + (size_t)(p.cls_w0 + p.sw * jx);
-        }
-        const size_t off = pixel * (size_t)p.d_cs + (size_t)(p.d_co + col);
-        if (addend) {
-          const float4 a = *reinterpret_cast<const float4*>(addend + off);
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
+      if (ok[g]) {
+        if (addend) { v.x += av[g].x; v.y += av[g].y; v.z += av[g].z; v.w += av[g].w; }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(dst + off) = v;
+        if (fuse) {
+          float a4[4] = {v.x, v.y, v.z, v.w};
+          const float x4[4] = {xv[g].x, xv[g].y, xv[g].z, xv[g].w};
+          const float y4[4] = {yv[g].x, yv[g].y, yv[g].z, yv[g].w};
+          bnr.visit_loaded(by != nullptr, x4, y4, a4);
+          v = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        }
+        *reinterpret_cast<float4*>(dst + off[g]) = v;
       }
     }
   };
   // block-wide: per-wave column sums in red[] -> one slab row per M-tile, waves added in fixed order (reproducible)
-  auto write_stats = [&]() __attribute__((always_inline)) {
+  auto write_stats = [&](float* slab, int row0) __attribute__((always_inline)) {
     __syncthreads();
     for (int c = tid; c < 2 * BN; c += NT) {
       const int which = c / BN, col = c - which * BN;
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += red[(w * 2 + which) * BN + col];
-      if (n0 + col < p.dC) p.stats[((size_t)(p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
+      if (n0 + col < p.dC) slab[((size_t)(row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
     }
   };
   const bool interior = m0 + BM <= p.M;          // block-uniform
@@ -294,7 +321,23 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
           red[(wave * 2 + 1) * BN + j * 16 + fr] = q;
         }
       }
-      write_stats();
+      write_stats(p.stats, p.stats_row0);
+    }
+    if constexpr (DGRAD) {
+      if (p.bnr_x) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s = bnr.s[e], q = bnr.q[e];
+#pragma unroll
+          for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+          if (lane < LPR) {
+            red[(wave * 2 + 0) * BN + lane * 4 + e] = s;
+            red[(wave * 2 + 1) * BN + lane * 4 + e] = q;
+          }
+        }
+        write_stats(p.bnr_slab, p.bnr_row0 + p.stats_row0);
+      }
     }
   }
 }

@@ -25,12 +25,15 @@ class BasicBlock:
         if stride != 1 or cin != planes:
             self.down = _cb(store, prefix, "downsample.0", "downsample.1", cin, planes, 1, stride, 0, trainable)
 
-    def __call__(self, ctx: Context, x: Act) -> Act:
+    def __call__(self, ctx: Context, x: Act, sole_consumer=False) -> Act:
+        """sole_consumer: nothing but this block reads x (the caller's promise).  Then conv1's dgrad completes x.grad
+        (the identity connection contributes earlier in the backward pass) and may carry the BatchNorm-backward
+        reduction of the layer that produced x (ConvBNAct: last_use); conv2 is the only reader of conv1's output."""
         # the downsample branch runs FIRST so that, in the reversed backward order, its dgrad comes after conv1's and
         # accumulates in place into x.grad: the stride-2 1x1 dgrad then touches only 1/4 of the pixels
         identity = x if self.down is None else self.down(ctx, x, relu=False)
-        out = self.c1(ctx, x, relu=True)
-        return self.c2(ctx, out, relu=True, residual=identity)
+        out = self.c1(ctx, x, relu=True, last_use=sole_consumer and self.down is None)
+        return self.c2(ctx, out, relu=True, residual=identity, last_use=True)
 
 
 class Bottleneck:
@@ -44,11 +47,11 @@ class Bottleneck:
         if stride != 1 or cin != planes * 4:
             self.down = _cb(store, prefix, "downsample.0", "downsample.1", cin, planes * 4, 1, stride, 0, trainable)
 
-    def __call__(self, ctx: Context, x: Act) -> Act:
+    def __call__(self, ctx: Context, x: Act, sole_consumer=False) -> Act:
         identity = x if self.down is None else self.down(ctx, x, relu=False)      # first: see BasicBlock
-        out = self.c1(ctx, x, relu=True)
-        out = self.c2(ctx, out, relu=True)
-        return self.c3(ctx, out, relu=True, residual=identity)
+        out = self.c1(ctx, x, relu=True, last_use=sole_consumer and self.down is None)
+        out = self.c2(ctx, out, relu=True, last_use=True)
+        return self.c3(ctx, out, relu=True, residual=identity, last_use=True)
 
 
 class ResNet:
@@ -78,7 +81,7 @@ class ResNet:
         if self.maxpool is not None:
             x = self.maxpool(ctx, x)
         for b in self.blocks:
-            x = b(ctx, x)
+            x = b(ctx, x, sole_consumer=True)
         x = self.avgpool(ctx, x)
         return self.fc(ctx, x)
 

@@ -39,13 +39,18 @@ def input_pad(c: int, dtype) -> int:
 
 class Act:
     """An NHWC activation (possibly a channel slice of a wider buffer) plus its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad", "grad_buf")
+    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = False):
         self.data = data
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
         self.grad_buf: Optional[torch.Tensor] = None   # preassigned gradient storage (slice of a concat grad)
+        # BatchNorm-backward fusion (nn/layers.py: ConvBNAct): bn_src = (bn, z, mask_from_x) when this activation is the
+        # output of a training-mode BatchNorm+ReLU; bn_slab = the partial sums of that BatchNorm's backward reduction,
+        # written by the dgrad that completed this activation's gradient (which it also masked)
+        self.bn_src = None
+        self.bn_slab: Optional[torch.Tensor] = None
 
     @property
     def shape(self):

@@ -9,11 +9,16 @@ Names of parameters follow torchvision so checkpoints interoperate with the refe
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from .. import ops
 from .engine import Act, Context, ParamStore, accumulate_grad, pad_to, side_stream, workspace
+
+
+# DPA_FUSE_BN_BWD=0: never fuse the BatchNorm-backward reduction into the dgrad epilogue (A/B switch)
+_FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
 
 
 def _pair(v):
@@ -118,8 +123,10 @@ class Conv2d:
         return (self.ksize != (1, 1) and tuple(x.shape[1:3]) == self.ksize and self.padding == (0, 0)
                 and x.is_contiguous() and x.shape[3] == self.store.cview(self.w).shape[3])
 
-    def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor):
-        """dy is the gradient w.r.t. the raw conv output (pre-activation).  Writes dW/db, accumulates dx."""
+    def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor, last_use=False):
+        """dy is the gradient w.r.t. the raw conv output (pre-activation).  Writes dW/db, accumulates dx.
+        last_use: this dgrad is the LAST contribution to x.grad (every other consumer of x ran later in the forward
+        pass) - it may then finish x's gradient for the BatchNorm that produced x (see _dgrad)."""
         st = self.store
         side = side_stream(ctx.device) if (self.trainable and x.needs_grad) else None
         if side is not None:
@@ -132,7 +139,7 @@ class Conv2d:
             with torch.cuda.stream(side):
                 self._wgrad(ctx, x, dy)
                 self._ev[1].record(side)
-            self._dgrad(ctx, x, dy)
+            self._dgrad(ctx, x, dy, last_use)
             main.wait_event(self._ev[1])
             self._ready(ctx)
             return
@@ -140,7 +147,7 @@ class Conv2d:
             self._wgrad(ctx, x, dy)
             self._ready(ctx)
         if x.needs_grad:
-            self._dgrad(ctx, x, dy)
+            self._dgrad(ctx, x, dy, last_use)
 
     def _ready(self, ctx):
         if self.b is not None:
@@ -160,7 +167,30 @@ class Conv2d:
         else:
             ops.conv_wgrad(dy, x.data, gw, self.ksize, self.stride, self.padding, workspace=ws)
 
-    def _dgrad(self, ctx, x, dy):
+    def _bn_fusion(self, ctx, x, gemm):
+        """x is the output of a BatchNorm+ReLU and this dgrad completes its gradient: let the epilogue apply the ReLU mask
+        and write the partial sums of that BatchNorm's backward reduction (one memory pass over dy, y and z saved;
+        csrc/hip/conv_common.h: BnReduceLane).  Needs a dgrad that writes every pixel (kernel >= stride)."""
+        if not (_FUSE_BN_BWD and x.bn_src is not None and not gemm and x.grad_buf is None
+                and self.ksize[0] >= self.stride[0] and self.ksize[1] >= self.stride[1]):
+            return None
+        # measured on ResNet-50, batch 1024 (profiles/r2_bn_bwd_fusion.txt): fp32 -6.5 ms per step (the removed kernel:
+        # -17.6 ms, the dgrad epilogues: +12 ms - their reads are exposed at the end of each tile); in bf16 the removed
+        # kernel moves half the bytes and the step got 2.5 ms SLOWER, so bf16 keeps the separate reduction
+        if x.data.dtype != torch.float32 and os.environ.get("DPA_FUSE_BN_BWD") != "force":
+            return None
+        bn, z, mask_from_x = x.bn_src
+        if z.shape != x.data.shape:
+            return None
+        a = bn.aux(ctx.device)
+        n, h, w, c = x.data.shape
+        rows = ops.bn_reduce_rows(n * h * w, self.stride, ctx.cuda)
+        slab = torch.empty((rows, 2, c), device=ctx.device, dtype=torch.float32)
+        if mask_from_x:
+            return (z, None, a[0], a[1], a[2], a[3], slab)
+        return (z, x.data, a[0], a[1], None, None, slab)
+
+    def _dgrad(self, ctx, x, dy, last_use=False):
         w = self.store.cview(self.w)
         gemm = self._as_gemm(x.data) and (x.grad is None or x.grad.is_contiguous()) \
             and (x.grad_buf is None or x.grad_buf.is_contiguous())
@@ -173,12 +203,15 @@ class Conv2d:
         wt3 = self._planes(ctx, self._wt, "_wt3")
         stride, padding = ((1, 1), (0, 0)) if gemm else (self.stride, self.padding)
         flat = (lambda t: t.view(t.shape[0], 1, 1, -1)) if gemm else (lambda t: t)
+        fuse = self._bn_fusion(ctx, x, gemm) if last_use else None
         if x.grad is None:
             dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
-            ops.conv_dgrad(dy, self._wt, flat(dx), stride, padding, wt3=wt3)
+            rows = ops.conv_dgrad(dy, self._wt, flat(dx), stride, padding, wt3=wt3, bn_reduce=fuse)
             x.grad = dx
         else:
-            ops.conv_dgrad(dy, self._wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3)
+            rows = ops.conv_dgrad(dy, self._wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3, bn_reduce=fuse)
+        if fuse is not None:
+            x.bn_slab = fuse[6][:rows]
 
     def __call__(self, ctx: Context, x: Act, relu=False, out=None) -> Act:
         y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
@@ -246,6 +279,20 @@ class BatchNorm2d:
         return dx_out
 
 
+def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m):
+    """BatchNorm2d.backward when a dgrad epilogue already masked dy and reduced it (Act.bn_slab)."""
+    st = bn.store
+    a = bn.aux(ctx.device)
+    dg = st.gview(bn.gamma) if bn.trainable else None
+    db = st.gview(bn.beta) if bn.trainable else None
+    ops.bn_bwd_from_slab(slab, m, a[0], a[1], st.view(bn.gamma), dg, db, a[4:6], a[6:9])
+    if bn.trainable:
+        ctx.tape.ready(bn.gamma)
+        ctx.tape.ready(bn.beta)
+    ops.bn_bwd_dx(dy, z, a[6:9], dx_out)
+    return dx_out
+
+
 def _stats_slab(ctx, m, c, conv_fused):
     rows = ops.stats_rows(m, c, ctx.cuda, ctx.dtype) if conv_fused else ops.bn_slab_rows(m, ctx.cuda)
     return workspace(ctx.device, rows * 2 * c, "bn_slab")[: rows * 2 * c].view(rows, 2, c)
@@ -257,7 +304,9 @@ class ConvBNAct:
     def __init__(self, conv: Conv2d, bn: BatchNorm2d):
         self.conv, self.bn = conv, bn
 
-    def __call__(self, ctx: Context, x: Act, relu=True, residual: Act = None, out=None) -> Act:
+    def __call__(self, ctx: Context, x: Act, relu=True, residual: Act = None, out=None, last_use=False) -> Act:
+        """last_use: no consumer of x comes after this layer in the backward pass, i.e. every other consumer of x (a
+        residual connection, a parallel branch) is called LATER in the forward pass - see Conv2d.backward_raw."""
         conv, bn = self.conv, self.bn
         n, h, w, _ = x.data.shape
         ho, wo = conv.out_hw(h, w)
@@ -273,14 +322,22 @@ class ConvBNAct:
         needs = x.needs_grad or conv.trainable or bn.trainable or (residual is not None and residual.needs_grad)
         y = Act(out, needs)
         if ctx.grad_enabled and needs:
+            mask_from_x = relu and residual is None and ctx.training
+            if relu and ctx.training:
+                y.bn_src = (bn, z, mask_from_x)      # a consumer's dgrad may do this BatchNorm's backward reduction
+
             def bw():
                 dy = y.grad
                 y.grad = None
-                dz = bn.backward(ctx, dy, y.data if relu else None, z, z,   # dx overwrites z (dead after this)
-                                 mask_from_x=relu and residual is None and ctx.training)
+                slab, y.bn_slab, y.bn_src = y.bn_slab, None, None
+                if slab is not None:       # dy arrived masked, its partial sums are in the slab
+                    dz = _bn_backward_from_slab(bn, ctx, dy, z, z, slab, m)
+                else:
+                    dz = bn.backward(ctx, dy, y.data if relu else None, z, z,   # dx overwrites z (dead after this)
+                                     mask_from_x=mask_from_x)
                 if residual is not None and residual.needs_grad:
                     accumulate_grad(residual, dy)                            # dy now holds dy*(y>0)
-                conv.backward_raw(ctx, x, dz)
+                conv.backward_raw(ctx, x, dz, last_use=last_use)
             ctx.tape.push(bw)
         return y
 

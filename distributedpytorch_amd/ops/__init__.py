@@ -20,7 +20,7 @@ def _hip():
 
 _TENSOR_OPS = [
     "conv_fprop", "conv_dgrad", "conv_wgrad", "transpose_krsc",
-    "bn_stats", "bn_finalize", "bn_eval_coeffs", "bn_apply", "bn_bwd_reduce", "bn_bwd_dx",
+    "bn_stats", "bn_finalize", "bn_eval_coeffs", "bn_apply", "bn_bwd_reduce", "bn_bwd_dx", "bn_bwd_from_slab",
     "relu_fwd", "relu_bwd", "add", "copy", "dropout", "rng_advance", "colsum",
     "maxpool_fwd", "maxpool_bwd", "avgpool_fwd", "avgpool_bwd",
     "ce_loss", "adam_step", "sgd_step", "advance_step", "cast", "augment_mnist",
@@ -68,6 +68,11 @@ def fp32_x6_active(cuda, dtype):
         return False
     from . import native
     return native.get_fp32_mode() == "x6"
+
+
+def bn_reduce_rows(n_pixels, stride, cuda):
+    """Upper bound on the slab rows conv_dgrad(bn_reduce=...) writes."""
+    return _hip().bn_reduce_rows(n_pixels, stride) if cuda else 1
 
 
 def bn_slab_rows(m, cuda):

@@ -74,9 +74,13 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     return y
 
 
-def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None):
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
     """dx = conv_transpose(dy, w).  wt is the filter transposed to [Cin, kh, kw, Cout] (reduction-contiguous).
-    addend (same geometry as dx) is added in the epilogue (gradient accumulation for fan-out)."""
+    addend (same geometry as dx) is added in the epilogue (gradient accumulation for fan-out).
+    bn_reduce = (x, y, mean, invstd, mask_scale, mask_shift, slab): dx is the COMPLETE gradient w.r.t. the output of a
+    BatchNorm(+ReLU) with input x; the epilogue masks the values it stores (y > 0, or mask_scale * x + mask_shift > 0)
+    and writes the per-tile partial sums (sum dz, sum dz * xhat) into slab [rows >= ceil(M / 64), 2, C].
+    Returns the number of slab rows written (0 without bn_reduce)."""
     lib = native.hip_lib()
     sh, sw = stride
     ph, pw = pad
@@ -94,10 +98,29 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None):
     assert wt.is_contiguous() and wt.shape[0] == p.dC and wt.shape[3] == p.sC
     if addend is not None:
         assert addend.stride() == dx.stride()
+    if bn_reduce is not None:
+        x, y, mean, invstd, mscale, mshift, slab = bn_reduce
+        assert p.R >= sh and p.S >= sw, "fused BN reduction: the dgrad has to write every pixel"
+        assert x.shape == dx.shape and x.dtype == dx.dtype and (y is None or (y.shape == dx.shape and y.dtype == dx.dtype))
+        n_px = dx.shape[0] * dx.shape[1] * dx.shape[2]
+        assert slab.dtype == torch.float32 and slab.is_contiguous() and slab.shape[0] >= bn_reduce_rows(n_px, stride) \
+            and tuple(slab.shape[1:]) == (2, p.dC)
+        p.bnr_x, p.bnr_cs = VP(x.data_ptr()), _check_nhwc(x, "bn x")
+        p.bnr_y, p.bnr_y_cs = (VP(y.data_ptr()), _check_nhwc(y, "bn y")) if y is not None else (VP(0), 0)
+        p.bnr_mean, p.bnr_invstd = VP(mean.data_ptr()), VP(invstd.data_ptr())
+        p.bnr_mscale, p.bnr_mshift = native.ptr(mscale), native.ptr(mshift)
+        p.bnr_slab = VP(slab.data_ptr())
     rc = lib.dpa_conv_igemm(ctypes.byref(p), _DT[dy.dtype], 1, native.stream_ptr())
     if rc:
         raise RuntimeError(f"dpa_conv_igemm(dgrad) rejected geometry rc={rc}")
-    return dx
+    return int(p.stats_rows_used) if bn_reduce is not None else 0
+
+
+def bn_reduce_rows(n_pixels, stride):
+    """Upper bound on the slab rows a conv_dgrad(bn_reduce=) over n_pixels writes: one per M-tile (>= 64 rows) of each of
+    the stride[0] * stride[1] parity classes."""
+    classes = stride[0] * stride[1]
+    return (n_pixels + 63) // 64 + classes
 
 
 def wgrad_workspace_numel(cout, rsc):

@@ -8,7 +8,7 @@ import torch
 
 from . import native
 from .hip_conv import (conv_dgrad, conv_fprop, conv_wgrad, out_size, stats_rows,  # noqa: F401
-                       wgrad_workspace_numel, _check_nhwc, split3_planes, last_stats_rows)
+                       wgrad_workspace_numel, _check_nhwc, split3_planes, last_stats_rows, bn_reduce_rows)
 from .native import F32, I32, I64, VP, ptr, stream_ptr
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
@@ -106,6 +106,15 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab
     _lib().dpa_bn_bwd_reduce(ptr(dy), dcs, ptr(y), ycs, ptr(x), xcs, ptr(mean), ptr(invstd), ptr(gamma), I64(m), c,
                              ptr(slab), ptr(scratch), ptr(dgamma), ptr(dbeta), ptr(sums), ptr(coef), int(accumulate),
                              _DT[dy.dtype], stream_ptr(), ptr(mask_scale), ptr(mask_shift))
+
+
+def bn_bwd_from_slab(slab, m, mean, invstd, gamma, dgamma, dbeta, sums, coef, scratch=None, accumulate=False):
+    """Finish a BatchNorm-backward reduction whose per-tile partial sums a dgrad epilogue wrote (conv_dgrad(bn_reduce=))."""
+    rows, c = slab.shape[0], slab.shape[2]
+    if scratch is None:
+        scratch = _scratch_f32(slab.device, ROWS_L2 * 2 * c, "bn")
+    _lib().dpa_bn_bwd_from_slab(ptr(slab), rows, ptr(mean), ptr(invstd), ptr(gamma), I64(m), c, ptr(scratch), ptr(dgamma),
+                                ptr(dbeta), ptr(sums), ptr(coef), int(accumulate), stream_ptr())
 
 
 def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None):

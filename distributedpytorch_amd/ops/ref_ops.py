@@ -49,7 +49,7 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     return y
 
 
-def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None):
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
     # wt: [Cin, kh, kw, Cout]  -> torch weight [Cout, Cin, kh, kw]
     w = wt.permute(3, 0, 1, 2).float()
     n, h, wd, c = dx.shape
@@ -57,8 +57,18 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None):
     g = _nhwc(g)
     if addend is not None:
         g = g + addend.float()
+    if bn_reduce is not None:       # fused BatchNorm-backward reduction (csrc/hip/conv_common.h: BnReduceLane)
+        x, y, mean, invstd, mscale, mshift, slab = bn_reduce
+        if y is not None:
+            g = g * (y > 0)
+        elif mscale is not None:
+            g = g * ((x.float() * mscale + mshift) > 0)
+        gs = g.to(dx.dtype).float().reshape(-1, c)
+        slab.zero_()
+        slab[0, 0] = gs.sum(0)
+        slab[0, 1] = (gs * ((x.float().reshape(-1, c) - mean) * invstd)).sum(0)
     dx.copy_(g.to(dx.dtype))
-    return dx
+    return 1
 
 
 def wgrad_workspace_numel(cout, rsc):
@@ -169,6 +179,23 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, gamma, dgamma, dbeta, sums, coef, slab
         else:
             dbeta.copy_(s)
     g = gamma if gamma is not None else torch.ones_like(mean)
+    a = g * invstd
+    b = -g * invstd * invstd * q / m
+    coef[0].copy_(a)
+    coef[1].copy_(b)
+    coef[2].copy_(-a * s / m - b * mean)
+
+
+def bn_bwd_from_slab(slab, m, mean, invstd, gamma, dgamma, dbeta, sums, coef, scratch=None, accumulate=False):
+    t = slab.sum(0)
+    s, q = t[0], t[1]
+    sums[0].copy_(s)
+    sums[1].copy_(q)
+    if dgamma is not None:
+        dgamma.copy_(dgamma + q if accumulate else q)
+    if dbeta is not None:
+        dbeta.copy_(dbeta + s if accumulate else s)
+    g = gamma if gamma is not None else torch.ones_like(invstd)
     a = g * invstd
     b = -g * invstd * invstd * q / m
     coef[0].copy_(a)

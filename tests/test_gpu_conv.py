@@ -189,3 +189,70 @@ def test_conv_presplit_x6_kernel(shape):
             torch.testing.assert_close(acc, acc0 + ref_dx, rtol=rt, atol=at * 10)
     finally:
         set_fp32_mode(prev)
+
+
+# (N, H, W, Cin(of the forward conv = channels of dx), Cout(channels of dy), k, stride, pad)
+BNR_SHAPES = [
+    (4, 28, 28, 128, 128, 3, 1, 1),     # pre-split x6 kernel (fp32), 128-wide tile
+    (4, 28, 28, 64, 256, 1, 1, 0),      # dC = 64: the narrow x6p / 256 x 64 tiles
+    (3, 30, 30, 128, 128, 3, 2, 1),     # stride 2: four parity classes, each with its own slab rows
+    (2, 17, 13, 24, 40, 3, 1, 1),       # general kernel (Cout of dy not a multiple of 32), partial tiles
+    (65, 32, 32, 128, 128, 3, 1, 1),    # tail-split launch
+]
+
+
+@pytest.mark.parametrize("mask", ["y", "x", "none"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", BNR_SHAPES)
+def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode):
+    """conv_dgrad(bn_reduce=...): the epilogue masks the gradient it stores and writes the partial sums of the
+    BatchNorm-backward reduction; compared with the unfused dgrad followed by the plain formulas in fp64."""
+    from distributedpytorch_amd.ops import hip_conv
+    if dtype == torch.bfloat16 and fp32_mode == "exact":
+        pytest.skip("the fp32 arithmetic mode does not affect the bf16 kernels")
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(99)
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g).to(dtype)
+    wt = (torch.randn(C, k, k, K, device="cuda", generator=g) * (k * k * K) ** -0.5).to(dtype)
+    z = (torch.randn(N, H, W, C, device="cuda", generator=g) * 2 + 0.5).to(dtype)      # the BatchNorm's input
+    mean = torch.randn(C, device="cuda", generator=g) * 0.3 + 0.5
+    invstd = torch.rand(C, device="cuda", generator=g) + 0.5
+    msc = torch.randn(C, device="cuda", generator=g)
+    msh = torch.randn(C, device="cuda", generator=g) * 0.2
+    y = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)                  # its (residual + ReLU) output
+    addend = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
+    wt3 = None
+    if dtype == torch.float32 and fp32_mode == "x6" and K % 32 == 0:
+        wt3 = hip_conv.split3_planes(wt, torch.empty(3 * wt.numel(), device="cuda", dtype=torch.bfloat16))
+    for use_addend in (False, True):
+        plain = torch.empty(N, H, W, C, device="cuda", dtype=dtype)
+        if use_addend:
+            plain.copy_(addend)
+        hip_conv.conv_dgrad(dy, wt, plain, (s, s), (pd, pd), addend=plain if use_addend else None, wt3=wt3)
+        if mask == "y":
+            keep = y > 0
+        elif mask == "x":
+            keep = (z.float() * msc + msh) > 0
+        else:
+            keep = torch.ones_like(z, dtype=torch.bool)
+        want = torch.where(keep, plain, torch.zeros_like(plain))
+        rows = hip_conv.bn_reduce_rows(N * H * W, (s, s))
+        slab = torch.full((rows, 2, C), float("nan"), device="cuda")
+        fused = torch.full((N, H, W, C), float("nan"), device="cuda", dtype=dtype)
+        if use_addend:
+            fused.copy_(addend)
+        used = hip_conv.conv_dgrad(dy, wt, fused, (s, s), (pd, pd), addend=fused if use_addend else None, wt3=wt3,
+                                   bn_reduce=(z, y if mask == "y" else None, mean, invstd,
+                                              msc if mask == "x" else None, msh if mask == "x" else None, slab))
+        assert 0 < used <= rows
+        assert torch.equal(fused, want)                      # same arithmetic, masked
+        got = slab[:used].double().sum(0)
+        assert torch.isfinite(got).all()
+        wd = want.double().reshape(-1, C)
+        xh = (z.double().reshape(-1, C) - mean.double()) * invstd.double()
+        ref_s, ref_q = wd.sum(0), (wd * xh).sum(0)
+        scale_s = wd.abs().sum(0).clamp_min(1e-6)
+        scale_q = (wd * xh).abs().sum(0).clamp_min(1e-6)
+        assert ((got[0] - ref_s).abs() / scale_s).max().item() < 2e-6
+        assert ((got[1] - ref_q).abs() / scale_q).max().item() < 2e-6

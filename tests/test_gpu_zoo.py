@@ -29,10 +29,21 @@ def test_zoo_gpu_fp32(name, cls, hw, n, gtol):
     assert abs(loss - ref_loss) < 1e-3 * max(1.0, abs(ref_loss))
     g = grads_by_name(net)
     gmax = max(p.grad.norm().item() for p in oracle.parameters())
+    # the same step in torch's own fp32 on the GPU: with 4-8 images per batch a ReLU whose pre-activation sits at the
+    # rounding level flips between implementations, so a parameter may miss the fixed bound in ANY fp32 implementation;
+    # such a parameter passes if our distance to fp64 is within twice torch-fp32's own distance to fp64
+    import copy
+    o32 = copy.deepcopy(oracle).float().cuda()
+    for q in o32.parameters():
+        q.grad = None
+    oracle_step(o32, x.cuda(), y.cuda())
+    g32 = {k: q.grad.detach().cpu() for k, q in o32.named_parameters()}
     for k, p in oracle.named_parameters():
         v = p.grad.float()
         err = (g[k] - v).norm().item()
-        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax, (k, err, v.norm().item())
+        err32 = (g32[k] - v).norm().item()
+        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax or err < 2 * err32, \
+            (k, err, err32, v.norm().item())
     logits_e, _, _ = framework_step(net, x, y, train=False)
     ref_e, _ = oracle_step(oracle, x.double(), y, train=False)
     torch.testing.assert_close(logits_e, ref_e.float(), rtol=5e-3, atol=5e-3)
