@@ -6,9 +6,10 @@
 //   comm stream:                                    wait(ready[s]) | ncclAllReduce(bucket k) | record(done[s])
 //
 // s = the slot the front (comm_api.cpp) assigned to the collective.  The ncclUniqueId travels through the C++ TCP
-// store (csrc/host/tcpstore.cpp).  The comm stream has the SAME priority as the compute stream: with a different
-// priority the two hardware queues waited on each other's barrier packets and hipDeviceSynchronize never returned
-// (docs/COMM.md); there is deliberately no knob for it.
+// store (csrc/host/tcpstore.cpp).  The comm stream has the SAME priority as the compute stream (as ProcessGroupNCCL's
+// does): round 1 saw intermittent hangs of hipDeviceSynchronize with a high-priority comm stream and none since the
+// priority is 0; round 2 could not reproduce the hang in either configuration (docs/COMM.md).  There is deliberately no
+// knob for it.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 

@@ -13,9 +13,11 @@ import torch.distributed as dist
 
 
 def warm_kernel_library(device):
-    """Load the gfx950 code object (one trivial launch + sync) before any RCCL communicator exists: on the ROCm 7.0
-    runtime a module first loaded AFTER ncclCommInitRank deadlocked later cross-stream event waits (measured with the
-    native communicator, scripts/debug/dbg_rccl5.py vs dbg_rccl6.py); loading it first costs ~ms once."""
+    """Load the gfx950 code object (one trivial launch + sync) before any RCCL communicator exists.  Defensive only:
+    round 1 suspected that a module first loaded AFTER ncclCommInitRank caused its intermittent hang, but the round-2
+    experiment (scripts/diag/rccl_module_order.py, docs/COMM.md) ran both orders, at normal and at high comm-stream
+    priority, without a hang - the order is not the cause.  Kept because it costs one launch and makes the first
+    training step's latency independent of the code-object load."""
     from .. import ops
     warm = torch.zeros(2, dtype=torch.int64, device=device)
     ops.rng_advance(warm)

@@ -73,10 +73,11 @@ class NativeComm:
         self._ctl_seq = 0
         dev_index = (self.device.index or 0) if on_gpu else -1
         if on_gpu:
-            # Load the kernel library's code object BEFORE any communicator exists (docs/COMM.md: a gfx950 module first
-            # loaded after ncclCommInitRank deadlocked later cross-stream event waits on the ROCm 7.0 runtime).
+            # Load the kernel library's code object before the communicator exists (defensive; docs/COMM.md: the order
+            # was suspected in round 1 and cleared by the round-2 experiment).
             from .comm import warm_kernel_library
-            warm_kernel_library(self.device)
+            if os.environ.get("DPA_DIAG_SKIP_WARM") != "1":       # (scripts/diag/rccl_module_order.py only)
+                warm_kernel_library(self.device)
         if self.transport == "rccl":
             n = self.lib.dpa_comm_unique_id_size()
             buf = ctypes.create_string_buffer(n)
