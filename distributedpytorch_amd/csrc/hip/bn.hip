@@ -140,7 +140,32 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
       sc[e] = a.x; sc[e + 1] = a.y; sc[e + 2] = a.z; sc[e + 3] = a.w;
       sh[e] = b.x; sh[e + 1] = b.y; sh[e + 2] = b.z; sh[e + 3] = b.w;
     }
-    for (long long m = r0 + rl; m < r1; m += rowLanes) {
+    // UNR rows per trip, every load issued before the first use: a streaming kernel needs the bytes in flight
+    // (one row per trip ran at 5.1 TB/s where torch's 4-wide add reaches 6.0: scripts/micro/hbm_bw.py)
+    constexpr int UNR = 4;
+    long long m = r0 + rl;
+    for (; m + (long long)(UNR - 1) * rowLanes < r1; m += (long long)UNR * rowLanes) {
+      Vec16<T> v[UNR], rv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u].load(x + (m + (long long)u * rowLanes) * x_cs + c);
+      if (res) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) rv[u].load(res + (m + (long long)u * rowLanes) * r_cs + c);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float f = v[u].get(e) * sc[e] + sh[e];
+          if (res) f += rv[u].get(e);
+          if (relu) f = fmaxf(f, 0.f);
+          o.set(e, f);
+        }
+        o.store(y + (m + (long long)u * rowLanes) * y_cs + c);
+      }
+    }
+    for (; m < r1; m += rowLanes) {
       Vec16<T> v; v.load(x + m * x_cs + c);
       Vec16<T> rv; if (res) rv.load(res + m * r_cs + c);
       Vec16<T> o;
@@ -272,14 +297,35 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
     float msc[VEC], msh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { msc[e] = mscale ? mscale[c + e] : 0.f; msh[e] = mscale ? mshift[c + e] : 1.f; }
-    for (long long m = r0 + rl; m < r1; m += rowLanes) {
+    constexpr int UNR = 4;                      // rows per trip, loads first (see bn_apply_kernel)
+    long long m = r0 + rl;
+    for (; m + (long long)(UNR - 1) * rowLanes < r1; m += (long long)UNR * rowLanes) {
+      Vec16<T> g[UNR], xv[UNR];                 // dx may alias x: each thread reads its chunks before writing them
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        g[u].load(dz + (m + (long long)u * rowLanes) * dz_cs + c);
+        xv[u].load(x + (m + (long long)u * rowLanes) * x_cs + c);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float xe = xv[u].get(e);
+          const float ge = (xe * msc[e] + msh[e] > 0.f) ? g[u].get(e) : 0.f;   // (no mask: 0*x + 1 > 0 always)
+          o.set(e, A[e] * ge + B[e] * xe + D[e]);
+        }
+        o.store(dx + (m + (long long)u * rowLanes) * dx_cs + c);
+      }
+    }
+    for (; m < r1; m += rowLanes) {
       Vec16<T> g; g.load(dz + m * dz_cs + c);
-      Vec16<T> xv; xv.load(x + m * x_cs + c);   // dx may alias x: each thread reads its chunk before writing it
+      Vec16<T> xv; xv.load(x + m * x_cs + c);
       Vec16<T> o;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float xe = xv.get(e);
-        const float ge = (xe * msc[e] + msh[e] > 0.f) ? g.get(e) : 0.f;      // (no mask: 0*x + 1 > 0 always)
+        const float ge = (xe * msc[e] + msh[e] > 0.f) ? g.get(e) : 0.f;
         o.set(e, A[e] * ge + B[e] * xe + D[e]);
       }
       o.store(dx + m * dx_cs + c);
@@ -287,10 +333,20 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
   }
 }
 
-static int ew_rows_per_block(long long M, int* nblocks) {
-  static const int target = [] { const char* e = getenv("DPA_BN_EW_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
-  long long rpb = (M + target - 1) / target;
-  if (rpb < 16) rpb = 16;
+// Row blocking of the streaming (elementwise) kernels: a block owns a CONTIGUOUS ~32 KiB of each operand and the grid
+// walks memory in block order, so the blocks resident at any time cover one moving window of the tensor - the access
+// pattern of torch's elementwise kernels, which stream at 6.0 TB/s here.  (The first version cut M into 2048 long
+// ranges, i.e. 2048 concurrent streams 1.6 MB apart: 5.1 TB/s.  scripts/micro/hbm_bw.py, profiles/r2_hbm_bw.txt.)
+static int ew_rows_per_block(long long M, int C, int elem_bytes, int* nblocks) {
+  static const int target_kb = [] { const char* e = getenv("DPA_BN_EW_KB"); int v = e ? atoi(e) : 0; return v > 0 ? v : 16; }();
+  // whole unrolled trips: the kernels move 4 rows per row-lane per trip (UNR in bn_apply_kernel / bn_bwd_dx_kernel)
+  const int cpr = C / (16 / elem_bytes);
+  const int row_lanes = 256 / (cpr < 256 ? (cpr > 0 ? cpr : 1) : 256);
+  const long long unit = 4LL * (row_lanes > 0 ? row_lanes : 1);
+  long long trips = ((long long)target_kb << 10) / (unit * C * elem_bytes);
+  if (trips < 1) trips = 1;
+  long long rpb = unit * trips;
+  while ((M + rpb - 1) / rpb > 0x7fffffffLL) rpb *= 2;
   *nblocks = (int)((M + rpb - 1) / rpb);
   return (int)rpb;
 }
@@ -345,7 +401,7 @@ DPA_API int dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, con
 }
 DPA_API int dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
                           int y_cs, long long M, int C, int relu, int dtype, hipStream_t s) {
-  int nb; const int rpb = ew_rows_per_block(M, &nb);
+  int nb; const int rpb = ew_rows_per_block(M, C, dtype == 1 ? 2 : 4, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
                                      (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb);
   else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
@@ -380,7 +436,7 @@ DPA_API int dpa_bn_bwd_from_slab(const float* slab, int rows, const float* mean,
 }
 DPA_API int dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
                            long long M, int C, int dtype, hipStream_t s, const float* mscale, const float* mshift) {
-  int nb; const int rpb = ew_rows_per_block(M, &nb);
+  int nb; const int rpb = ew_rows_per_block(M, C, dtype == 1 ? 2 : 4, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
                                      (const bf16_t*)x, x_cs, coef, (bf16_t*)dx, dx_cs, M, C, rpb, mscale, mshift);
   else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, dz_cs,
