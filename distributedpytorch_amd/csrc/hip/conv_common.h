@@ -54,6 +54,12 @@ struct ConvParams {
   int bnr_cs, bnr_y_cs;
   int bnr_row0;              // first slab row of this parity class (host)
   int bnr_pad;
+  // EXPERIMENT (scripts/bench_norm_on_load.py, docs/KERNELS.md §4): fprop applies relu(src * nol_scale[c] + nol_shift[c])
+  // to the activation fragments before the split ("normalise-on-load").  Padding pixels are NOT handled (they would
+  // have to stay zero after the transform), so only 1x1 / unpadded problems are numerically meaningful; the 3x3
+  // timing is representative.  Not used by the framework.
+  const float* nol_scale;
+  const float* nol_shift;
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;

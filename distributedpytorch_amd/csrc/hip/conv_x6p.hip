@@ -57,7 +57,7 @@ DPA_API int dpa_split3_planes(const float* w, void* out, long long n, hipStream_
 
 // NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
 // 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
-template <int TN, bool DGRAD, int NW, int MF>
+template <int TN, bool DGRAD, int NW, int MF, bool NOL = false>
 __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p) {
   constexpr int BM = 32 * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
   constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
@@ -251,6 +251,19 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
         for (int part = 0; part < 3; ++part)
           bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
       if constexpr (TN <= 4) { if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1); }
+      if constexpr (NOL) {      // experiment: relu(x * scale[c] + shift[c]) on the lane's 8 reduction elements (channels)
+        const int cb = (kt * BKE) % p.sC + 8 * fq;
+        const float4 s0 = *reinterpret_cast<const float4*>(p.nol_scale + cb), s1 = *reinterpret_cast<const float4*>(p.nol_scale + cb + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(p.nol_shift + cb), h1 = *reinterpret_cast<const float4*>(p.nol_shift + cb + 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          uint4& lo = fa[0][i]; uint4& hi = fa[1][i];
+          lo.x = __float_as_uint(fmaxf(__uint_as_float(lo.x) * s0.x + h0.x, 0.f)); lo.y = __float_as_uint(fmaxf(__uint_as_float(lo.y) * s0.y + h0.y, 0.f));
+          lo.z = __float_as_uint(fmaxf(__uint_as_float(lo.z) * s0.z + h0.z, 0.f)); lo.w = __float_as_uint(fmaxf(__uint_as_float(lo.w) * s0.w + h0.w, 0.f));
+          hi.x = __float_as_uint(fmaxf(__uint_as_float(hi.x) * s1.x + h1.x, 0.f)); hi.y = __float_as_uint(fmaxf(__uint_as_float(hi.y) * s1.y + h1.y, 0.f));
+          hi.z = __float_as_uint(fmaxf(__uint_as_float(hi.z) * s1.z + h1.z, 0.f)); hi.w = __float_as_uint(fmaxf(__uint_as_float(hi.w) * s1.w + h1.w, 0.f));
+        }
+      }
       uint4 ap[TM][3];
 #pragma unroll
       for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
@@ -353,6 +366,7 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
   if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF>), grid, block, lds, s, p);
+  else if (p.nol_scale) hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, true>), grid, block, lds, s, p);
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
 }
 
