@@ -249,6 +249,9 @@ class Tape:
     def __init__(self):
         self.fns: List[Callable[[], None]] = []
         self.param_ready_hook: Optional[Callable[[ParamSpec], None]] = None
+        # weight-gradient kernels running on the side stream whose join with the main stream is still outstanding:
+        # (done event, callback run after the join, tensors the side-stream kernels read - kept alive until the join)
+        self.side_pending: List[tuple] = []
 
     def push(self, fn):
         self.fns.append(fn)
@@ -256,6 +259,18 @@ class Tape:
     def backward(self):
         while self.fns:
             self.fns.pop()()
+        self.join_side(0)
+
+    def defer_side(self, done_event, after_join, keep_alive):
+        self.side_pending.append((done_event, after_join, keep_alive))
+
+    def join_side(self, keep: int):
+        """Make the current stream wait for all but the newest `keep` side-stream jobs, oldest first, and run their
+        callbacks (gradient-ready announcements: they must be ordered after the kernels that wrote the gradients)."""
+        while len(self.side_pending) > keep:
+            ev, after, _refs = self.side_pending.pop(0)
+            torch.cuda.current_stream().wait_event(ev)
+            after()
 
     def ready(self, spec):
         """Called by a layer when the gradient of `spec` is final for this step (feeds the DDP reducer)."""
@@ -290,9 +305,12 @@ _workspaces = {}
 
 
 _side_streams = {}
-# opt-in (DPA_BWD_STREAMS=2): measured +0.7 % on ResNet-50 fp32 and +0 % on bf16 (the conv kernels already fill the
-# chip), not worth a third stream next to RCCL's by default
+# DPA_BWD_STREAMS=2: weight-gradient kernels on a second stream.  Joining right after the layer's own dgrad gained
+# nothing (+0.7 % fp32, +0 % bf16: two MFMA-bound kernels share the matrix pipes).  With the join DEFERRED by
+# DPA_BWD_LAG layers (nn/layers.py: Conv2d.backward_raw) the wgrad of layer k also overlaps the memory-bound
+# BatchNorm-backward kernels of the layers below it.
 DUAL_STREAM_BACKWARD = os.environ.get("DPA_BWD_STREAMS", "1") == "2"
+BWD_LAG = int(os.environ.get("DPA_BWD_LAG", "2"))
 
 
 def side_stream(device):

@@ -14,7 +14,7 @@ import os
 import torch
 
 from .. import ops
-from .engine import Act, Context, ParamStore, accumulate_grad, pad_to, side_stream, workspace
+from .engine import BWD_LAG, Act, Context, ParamStore, accumulate_grad, pad_to, side_stream, workspace
 
 
 # DPA_FUSE_BN_BWD=0: never fuse the BatchNorm-backward reduction into the dgrad epilogue (A/B switch)
@@ -130,20 +130,27 @@ class Conv2d:
         st = self.store
         side = side_stream(ctx.device) if (self.trainable and x.needs_grad) else None
         if side is not None:
-            # fork: wgrad (+ bias grad) on the side stream, dgrad on the main stream, join before anything else runs
+            # fork: wgrad on the side stream, dgrad (and everything after it) on the main stream.  The join is deferred:
+            # the main stream waits for this wgrad only BWD_LAG conv layers further down the tape (or at the end of
+            # backward), so it overlaps the MFMA-bound dgrads AND the memory-bound BatchNorm-backward kernels in between.
+            tape = ctx.tape
+            tape.join_side(max(BWD_LAG - 1, 0))
+            if self.b is not None:
+                ops.colsum(dy, st.gview(self.b))      # (shares scratch with main-stream kernels: stays on the main stream)
             if self._ev is None:
                 self._ev = (torch.cuda.Event(), torch.cuda.Event())
             main = torch.cuda.current_stream()
             self._ev[0].record(main)
             side.wait_event(self._ev[0])
             with torch.cuda.stream(side):
-                self._wgrad(ctx, x, dy)
+                self._wgrad(ctx, x, dy, bias=False)
                 self._ev[1].record(side)
+            tape.defer_side(self._ev[1], lambda: self._ready(ctx), (dy, x.data))
             self._dgrad(ctx, x, dy, last_use)
-            main.wait_event(self._ev[1])
-            self._ready(ctx)
             return
         if self.trainable:
+            if ctx.tape.side_pending:
+                ctx.tape.join_side(0)        # this wgrad runs on the main stream and shares the split-K workspace
             self._wgrad(ctx, x, dy)
             self._ready(ctx)
         if x.needs_grad:
@@ -154,9 +161,9 @@ class Conv2d:
             ctx.tape.ready(self.b)
         ctx.tape.ready(self.w)
 
-    def _wgrad(self, ctx, x, dy):
+    def _wgrad(self, ctx, x, dy, bias=True):
         st = self.store
-        if self.b is not None:
+        if bias and self.b is not None:
             ops.colsum(dy, st.gview(self.b))
         rsc = self.ksize[0] * self.ksize[1] * x.data.shape[3]
         ws = workspace(ctx.device, ops.wgrad_workspace_numel(pad_to(self.cout), rsc, ctx.cuda), "wgrad") if ctx.cuda else None
