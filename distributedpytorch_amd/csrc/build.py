@@ -52,6 +52,17 @@ def _compile(cmd, src, obj, stamp, digest):
     return src, r.stderr
 
 
+def _check_kernel_stubs(so):
+    """A kernel whose body does not compile in the HOST pass (a device-only type or builtin outside a
+    __HIP_DEVICE_COMPILE__ guard inside a template) silently loses its launch stub and the library then fails to load
+    on the GPU box with 'undefined symbol: __device_stub__...'.  Catch that here, where the build runs."""
+    r = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True)
+    missing = [l.split()[-1] for l in r.stdout.splitlines() if "__device_stub__" in l]
+    if missing:
+        raise RuntimeError(f"{os.path.basename(so)}: kernel launch stubs missing (host pass did not instantiate them): "
+                           + ", ".join(missing[:4]))
+
+
 def build(force=False, jobs=None, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -95,6 +106,7 @@ def build(force=False, jobs=None, verbose=True):
         # kernels and torch share ONE HIP runtime (streams/events/pointers are interchangeable).
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", hip_so] + objs["hip"]
         subprocess.run(cmd, check=True)
+        _check_kernel_stubs(hip_so)
         if verbose:
             print(f"[build] linked {os.path.relpath(hip_so, PKG)}", flush=True)
     if objs["host"] and (relink or not os.path.exists(host_so)):
