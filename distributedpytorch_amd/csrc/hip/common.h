@@ -72,6 +72,54 @@ __device__ __forceinline__ float wave_max(float v) {
 static inline int dpa_launch_rc() { return (int)hipGetLastError(); }
 
 // Memory-bound grid sizing: cap at 256 CUs x 8 blocks and grid-stride the rest.
+// Pooling geometry (pool.hip; also the fused BatchNorm + max-pool backward in bn.hip)
+struct PoolP {
+  int N, H, W, C, Ho, Wo;
+  int kh, kw, sh, sw, ph, pw;
+  int x_cs, y_cs;
+};
+
+#ifdef __HIPCC__
+// Gradient of a max-pool w.r.t. input pixel (n, hi, wi), channels c .. c + VEC: the sum of dy over the (few) windows that
+// cover the pixel and whose recorded argmax is this tap.  Gather style: no atomics, deterministic.
+__device__ __forceinline__ int div_small(int a, int s) {      // a >= 0; strides are 1 or 2 in every model of the zoo
+  return s == 1 ? a : (s == 2 ? (a >> 1) : a / s);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void maxpool_gather_grad(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                    const PoolP& p, int dy_cs, int n, int hi, int wi, int c, float (&acc)[VEC]) {
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  // ho*sh - ph + r == hi  with 0 <= r < kh
+  int ho_lo = (hi + p.ph - p.kh + 1 <= 0) ? 0 : div_small(hi + p.ph - p.kh + p.sh, p.sh);
+  int ho_hi = div_small(hi + p.ph, p.sh); if (ho_hi >= p.Ho) ho_hi = p.Ho - 1;
+  int wo_lo = (wi + p.pw - p.kw + 1 <= 0) ? 0 : div_small(wi + p.pw - p.kw + p.sw, p.sw);
+  int wo_hi = div_small(wi + p.pw, p.sw); if (wo_hi >= p.Wo) wo_hi = p.Wo - 1;
+  for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+    const int r = hi + p.ph - ho * p.sh;
+    if (r < 0 || r >= p.kh) continue;
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      const int s = wi + p.pw - wo * p.sw;
+      if (s < 0 || s >= p.kw) continue;
+      const unsigned char tap = (unsigned char)(r * p.kw + s);
+      const long long opix = (long long)(n * p.Ho + ho) * p.Wo + wo;
+      Vec16<T> g; g.load(dy + opix * dy_cs + c);
+      const unsigned char* ip = idx + opix * p.C + c;
+      unsigned char bi[VEC];
+      if (VEC == 8) { uint2 pk = *reinterpret_cast<const uint2*>(ip); const unsigned char* b = (const unsigned char*)&pk;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) bi[e] = b[e];
+      } else { uint32_t pk = *reinterpret_cast<const uint32_t*>(ip); const unsigned char* b = (const unsigned char*)&pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[e] = b[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) if (bi[e] == tap) acc[e] += g.get(e);
+    }
+  }
+}
+#endif
+
 static inline int dpa_grid(long long work_items, int block) {
   long long g = (work_items + block - 1) / block;
   if (g < 1) g = 1;

@@ -10,7 +10,8 @@ from __future__ import annotations
 
 from .. import ops
 from ..nn.engine import Act, Context, ParamStore, accumulate_grad
-from ..nn.layers import (AvgPool2d, BatchNorm2d, BNAct, Conv2d, ConvBNAct, Linear, MaxPool2d, kaiming_normal_fan_out, zeros_)
+from ..nn.layers import (AvgPool2d, BatchNorm2d, BNAct, Conv2d, ConvBNAct, ConvBNReLUPool, Linear, MaxPool2d,
+                         kaiming_normal_fan_out, zeros_)
 
 
 def _kn(t):
@@ -89,6 +90,7 @@ class DenseNet:
         conv0 = Conv2d(store, "features.conv0", 3, init_features, 7, 2, 3, bias=False, w_init=_kn, trainable=t)
         self.stem = ConvBNAct(conv0, BatchNorm2d(store, "features.norm0", init_features, trainable=t))
         self.pool0 = MaxPool2d(3, 2, 1)
+        self.stem_pool = ConvBNReLUPool(conv0, self.stem.bn, self.pool0)      # fused conv0-norm0-relu0-pool0 (nn/layers.py)
         self.blocks, self.transitions = [], []
         c = init_features
         for i, n in enumerate(block_config):
@@ -103,11 +105,14 @@ class DenseNet:
         self.classifier = Linear(store, "classifier", c, num_classes, b_init=zeros_, trainable=True)
 
     def forward(self, ctx: Context, x: Act):
-        x = self.stem(ctx, x, relu=True)
-        n, h, w, _ = x.data.shape
-        h, w = ops.pool_out_size(h, 3, 2, 1), ops.pool_out_size(w, 3, 2, 1)
-        buf = self.blocks[0].alloc(ctx, n, h, w)
-        y = self.pool0(ctx, x, out=buf[..., : self.blocks[0].cin])
+        bufs = []
+
+        def first_slice(n_, hp, wp):
+            bufs.append(self.blocks[0].alloc(ctx, n_, hp, wp))
+            return bufs[0][..., : self.blocks[0].cin]
+        y = self.stem_pool(ctx, x, out_fn=first_slice)
+        buf = bufs[0]
+        n, h, w = buf.shape[0], buf.shape[1], buf.shape[2]
         for i, blk in enumerate(self.blocks):
             xt = blk(ctx, y, buf)
             if i < len(self.transitions):

@@ -4,8 +4,15 @@ and ResNet-50 (BASELINE.json config 5).  Parameter names, registration order and
 """
 from __future__ import annotations
 
+import os
+
 from ..nn.engine import Act, Context, ParamStore
-from ..nn.layers import (AvgPool2d, BatchNorm2d, Conv2d, ConvBNAct, Linear, MaxPool2d, kaiming_normal_fan_out)
+from ..nn.layers import (AvgPool2d, BatchNorm2d, Conv2d, ConvBNAct, ConvBNReLUPool, Linear, MaxPool2d,
+                         kaiming_normal_fan_out)
+
+
+# DPA_FUSE_STEM_POOL=0: stem as conv+BN+ReLU followed by a separate max-pool (A/B switch for nn/layers.py:ConvBNReLUPool)
+_FUSE_STEM_POOL = os.environ.get("DPA_FUSE_STEM_POOL", "1") != "0"
 
 
 def _cb(store, prefix, conv_name, bn_name, cin, cout, k, stride, pad, trainable):
@@ -66,6 +73,7 @@ class ResNet:
         else:
             self.stem = _cb(store, "", "conv1", "bn1", 3, 64, 7, 2, 3, t)
             self.maxpool = MaxPool2d(3, 2, 1)
+            self.stem_pool = ConvBNReLUPool(self.stem.conv, self.stem.bn, self.maxpool)      # fused stem (nn/layers.py)
         self.blocks = []
         cin = 64
         for li, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
@@ -77,9 +85,12 @@ class ResNet:
         self.fc = Linear(store, "fc", cin, num_classes, bias=True, trainable=True)
 
     def forward(self, ctx: Context, x: Act):
-        x = self.stem(ctx, x, relu=True)
-        if self.maxpool is not None:
-            x = self.maxpool(ctx, x)
+        if self.maxpool is not None and _FUSE_STEM_POOL:
+            x = self.stem_pool(ctx, x)
+        else:
+            x = self.stem(ctx, x, relu=True)
+            if self.maxpool is not None:
+                x = self.maxpool(ctx, x)
         for b in self.blocks:
             x = b(ctx, x, sole_consumer=True)
         x = self.avgpool(ctx, x)

@@ -349,6 +349,49 @@ class ConvBNAct:
         return y
 
 
+class ConvBNReLUPool:
+    """conv -> BatchNorm -> ReLU -> MaxPool as one unit (the ResNet / DenseNet stem).  Forward: the full-resolution
+    BatchNorm output is never materialised - the pool reads the conv output through the folded BatchNorm coefficients +
+    ReLU (`maxpool_fwd(scale=, shift=)`): one write and one read of a 3.3 GB tensor less per ResNet-50 step at batch 1024.
+    Backward: max-pool backward into a full-resolution gradient, then the usual BatchNorm backward with the ReLU mask
+    recomputed from the conv output.  (Gathering the pooled gradient through the argmax indices inside the two
+    BatchNorm-backward kernels was measured too: 5.9 ms against 4.85 ms for the separate kernels - the gather runs
+    twice - so it is not done.)"""
+
+    def __init__(self, conv: Conv2d, bn: BatchNorm2d, pool: "MaxPool2d"):
+        self.conv, self.bn, self.pool = conv, bn, pool
+
+    def __call__(self, ctx: Context, x: Act, out_fn=None) -> Act:
+        """out_fn(n, hp, wp) -> the tensor to pool into (e.g. a channel slice of a concat buffer); default: a new one."""
+        conv, bn, pool = self.conv, self.bn, self.pool
+        n, h, w, _ = x.data.shape
+        ho, wo = conv.out_hw(h, w)
+        m, cp = n * ho * wo, pad_to(conv.cout)
+        slab = _stats_slab(ctx, m, cp, True) if ctx.training else None
+        z = conv.forward_raw(ctx, x.data, stats=slab, stats_shift=bn.stat_shift(ctx))
+        if slab is not None:
+            slab = slab[: conv.last_stats_rows]
+        a = bn.coeffs(ctx, slab, m)
+        hp = ops.pool_out_size(ho, pool.ksize[0], pool.stride[0], pool.padding[0], pool.ceil_mode)
+        wp = ops.pool_out_size(wo, pool.ksize[1], pool.stride[1], pool.padding[1], pool.ceil_mode)
+        needs = x.needs_grad or conv.trainable or bn.trainable
+        track = ctx.grad_enabled and needs
+        out = ctx.empty((n, hp, wp, cp)) if out_fn is None else out_fn(n, hp, wp)
+        idx = torch.empty((n, hp, wp, cp), device=ctx.device, dtype=torch.uint8) if track else None
+        ops.maxpool_fwd(z, out, idx, pool.ksize, pool.stride, pool.padding, scale=a[2], shift=a[3])
+        y = Act(out, needs)
+        if track:
+            def bw():
+                dyp = y.grad
+                y.grad = None
+                dy = ctx.empty((n, ho, wo, cp))
+                ops.maxpool_bwd(dyp, idx, dy, pool.ksize, pool.stride, pool.padding)
+                dz = bn.backward(ctx, dy, None, z, z, mask_from_x=True)      # dx overwrites z (dead after this)
+                conv.backward_raw(ctx, x, dz)
+            ctx.tape.push(bw)
+        return y
+
+
 class BNAct:
     """Stand-alone BatchNorm (+ReLU) on an arbitrary (possibly channel-sliced) activation: DenseNet pre-activation."""
 

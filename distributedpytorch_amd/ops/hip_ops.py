@@ -189,10 +189,11 @@ def _poolp(x, y, ksize, stride, pad):
     return p
 
 
-def maxpool_fwd(x, y, idx, ksize, stride, pad):
+def maxpool_fwd(x, y, idx, ksize, stride, pad, scale=None, shift=None):
+    """scale / shift (per channel): pool relu(x * scale + shift) instead of x (BatchNorm-apply + ReLU folded in)."""
     p = _poolp(x, y, ksize, stride, pad)
-    assert ksize[0] * ksize[1] <= 255
-    _lib().dpa_maxpool_fwd(ptr(x), ptr(y), ptr(idx), ctypes.byref(p), _DT[x.dtype], stream_ptr())
+    assert ksize[0] * ksize[1] <= 255 and (scale is None) == (shift is None)
+    _lib().dpa_maxpool_fwd(ptr(x), ptr(y), ptr(idx), ctypes.byref(p), _DT[x.dtype], stream_ptr(), ptr(scale), ptr(shift))
     return y
 
 

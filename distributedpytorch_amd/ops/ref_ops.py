@@ -270,7 +270,9 @@ def pool_out_size(h, k, s, p, ceil_mode=False):
     return (h + 2 * p - k) // s + 1
 
 
-def maxpool_fwd(x, y, idx, ksize, stride, pad):
+def maxpool_fwd(x, y, idx, ksize, stride, pad, scale=None, shift=None):
+    if scale is not None:
+        x = (x.float() * scale + shift).clamp_min(0).to(x.dtype)
     n, h, w, c = x.shape
     ho, wo = y.shape[1], y.shape[2]
     # emulate ceil_mode by padding -inf on the bottom/right as needed

@@ -297,3 +297,29 @@ def test_augment_mnist(dtype):
     assert torch.equal(o1, o2) and not torch.equal(o1, o3)
     lo, hi = (0 - 0.1307) / 0.3081, (1 - 0.1307) / 0.3081
     assert o1[..., 0].float().min().item() >= lo - 0.05 and o1[..., 0].float().max().item() <= hi + 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 28, 28, 64, 3, 2, 1), (2, 17, 13, 32, 3, 2, 1), (3, 12, 12, 16, 2, 2, 0)])
+def test_fused_bn_relu_maxpool_forward(shape, dtype):
+    """maxpool_fwd(scale=, shift=) == maxpool(relu(x * scale + shift)), values and argmax taps, bit for bit."""
+    from distributedpytorch_amd.ops import hip_ops as H
+    n, h, w, c, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    z = torch.randn(n, h, w, c, device="cuda", generator=g).to(dtype)
+    sc = torch.rand(c, device="cuda", generator=g) + 0.5
+    sh = torch.randn(c, device="cuda", generator=g) * 0.3
+    mean = torch.randn(c, device="cuda", generator=g) * 0.1
+    invstd = torch.rand(c, device="cuda", generator=g) + 0.5
+    gamma = torch.rand(c, device="cuda", generator=g) + 0.5
+    ho, wo = H.pool_out_size(h, k, s, pd), H.pool_out_size(w, k, s, pd)
+    # forward
+    act = torch.empty_like(z)
+    H.bn_apply(z, sc, sh, act, relu=True)
+    ref_y = torch.empty(n, ho, wo, c, device="cuda", dtype=dtype)
+    ref_i = torch.empty(n, ho, wo, c, device="cuda", dtype=torch.uint8)
+    H.maxpool_fwd(act, ref_y, ref_i, (k, k), (s, s), (pd, pd))
+    y = torch.empty_like(ref_y)
+    idx = torch.empty_like(ref_i)
+    H.maxpool_fwd(z, y, idx, (k, k), (s, s), (pd, pd), scale=sc, shift=sh)
+    assert torch.equal(y, ref_y) and torch.equal(idx, ref_i)

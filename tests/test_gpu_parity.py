@@ -93,7 +93,7 @@ def test_bn_variance_with_large_mean_small_std():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [((2, 56, 56, 64), 3, 2, 1, False), ((2, 27, 27, 64), 3, 2, 0, False),
+@pytest.mark.parametrize("cfg", [((2, 56, 56, 64), 3, 2, 1, False), ((2, 27, 27, 64), 3, 2, 0, False), ((3, 17, 13, 32), 3, 2, 1, False),
                                  ((2, 27, 27, 96), 3, 2, 0, True), ((2, 14, 14, 128), 2, 2, 0, False)])
 def test_maxpool_backward_per_element_vs_torch_autograd(cfg, dtype):
     """Tie-free input (a random permutation of distinct values per channel plane), so the argmax tap is unique and the
