@@ -374,8 +374,13 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
 bool dpa_x6p_eligible(const ConvParams& p) {
   static const int enabled = [] { const char* e = getenv("DPA_X6P"); return (e && e[0] == '0') ? 0 : 1; }();
   static const int min_kt = [] { const char* e = getenv("DPA_X6P_MINKT"); return e ? atoi(e) : 2; }();
+  static const int min_tiles = [] { const char* e = getenv("DPA_X6P_MIN_TILES"); return e ? atoi(e) : 256; }();
   const int ntaps = p.nR * p.nS;
-  return enabled && p.wgt3 && (p.sC % 32 == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni && p.Kg >= 32 * min_kt && p.dC >= 16;
+  // Only where its 128 x 128 (128 x 64) tiles fill the chip: skinny problems (Linear layers, small batches) need the
+  // general kernel's split-K / small tiles, and dC <= 32 (DenseNet growth convs) its 128 x 32 tile.
+  const long long tiles = (long long)((p.M + 127) / 128) * ((p.dC + (p.dC <= 64 ? 63 : 127)) / (p.dC <= 64 ? 64 : 128));
+  return enabled && p.wgt3 && (p.sC % 32 == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni && p.Kg >= 32 * min_kt && p.dC > 32 &&
+         tiles >= min_tiles;
 }
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
