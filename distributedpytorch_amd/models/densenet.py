@@ -56,8 +56,8 @@ class DenseBlock:
                     ops.add(G[..., :c], g, G[..., :c])
                 ctx.tape.push(add_into_g)                                              # after this layer's norm1 backward
             h = layer.norm1(ctx, xl, relu=True)
-            h = layer.conv1_norm2(ctx, h, relu=True)
-            yl = layer.conv2(ctx, h, out=buf[..., c: c + self.growth])
+            h = layer.conv1_norm2(ctx, h, relu=True, last_use=True)      # sole reader of norm1's output
+            yl = layer.conv2(ctx, h, out=buf[..., c: c + self.growth], last_use=True)
             if rec:
                 def set_grad(yl=yl, c=c):
                     yl.grad = st["G"][..., c: c + self.growth]
@@ -79,7 +79,7 @@ class Transition:
 
     def __call__(self, ctx, x: Act, out) -> Act:
         h = self.norm(ctx, x, relu=True)
-        h = self.conv(ctx, h)
+        h = self.conv(ctx, h, last_use=True)
         return self.pool(ctx, h, out=out)
 
 

@@ -45,8 +45,8 @@ class InceptionA:
         n, h, w, _ = x.data.shape
         buf, s = concat_buffer(ctx, n, h, w, self.widths)
         a = self.b1(ctx, x, out=s[0])
-        b = self.b5_2(ctx, self.b5_1(ctx, x), out=s[1])
-        c = self.d3(ctx, self.d2(ctx, self.d1(ctx, x)), out=s[2])
+        b = self.b5_2(ctx, self.b5_1(ctx, x), out=s[1], last_use=True)
+        c = self.d3(ctx, self.d2(ctx, self.d1(ctx, x), last_use=True), out=s[2], last_use=True)
         d = self.bp(ctx, self.pool(ctx, x), out=s[3])
         return concat(ctx, buf, [a, b, c, d])
 
@@ -65,7 +65,7 @@ class InceptionB:
         ho, wo = _out_hw(h, w, 3, 2, 0)
         buf, s = concat_buffer(ctx, n, ho, wo, self.widths)
         a = self.b3(ctx, x, out=s[0])
-        b = self.d3(ctx, self.d2(ctx, self.d1(ctx, x)), out=s[1])
+        b = self.d3(ctx, self.d2(ctx, self.d1(ctx, x), last_use=True), out=s[1], last_use=True)
         c = self.pool(ctx, x, out=s[2])
         return concat(ctx, buf, [a, b, c])
 
@@ -89,8 +89,9 @@ class InceptionC:
         n, h, w, _ = x.data.shape
         buf, s = concat_buffer(ctx, n, h, w, self.widths)
         a = self.b1(ctx, x, out=s[0])
-        b = self.s3(ctx, self.s2(ctx, self.s1(ctx, x)), out=s[1])
-        c = self.d5(ctx, self.d4(ctx, self.d3(ctx, self.d2(ctx, self.d1(ctx, x)))), out=s[2])
+        b = self.s3(ctx, self.s2(ctx, self.s1(ctx, x), last_use=True), out=s[1], last_use=True)
+        c = self.d5(ctx, self.d4(ctx, self.d3(ctx, self.d2(ctx, self.d1(ctx, x), last_use=True), last_use=True), last_use=True),
+                    out=s[2], last_use=True)
         d = self.bp(ctx, self.pool(ctx, x), out=s[3])
         return concat(ctx, buf, [a, b, c, d])
 
@@ -110,8 +111,8 @@ class InceptionD:
         n, h, w, _ = x.data.shape
         ho, wo = _out_hw(h, w, 3, 2, 0)
         buf, s = concat_buffer(ctx, n, ho, wo, self.widths)
-        a = self.a2(ctx, self.a1(ctx, x), out=s[0])
-        b = self.b4(ctx, self.b3(ctx, self.b2(ctx, self.b1(ctx, x))), out=s[1])
+        a = self.a2(ctx, self.a1(ctx, x), out=s[0], last_use=True)
+        b = self.b4(ctx, self.b3(ctx, self.b2(ctx, self.b1(ctx, x), last_use=True), last_use=True), out=s[1], last_use=True)
         c = self.pool(ctx, x, out=s[2])
         return concat(ctx, buf, [a, b, c])
 
@@ -135,10 +136,10 @@ class InceptionE:
         buf, s = concat_buffer(ctx, n, h, w, self.widths)
         o0 = self.b1(ctx, x, out=s[0])
         a = self.a1(ctx, x)
-        o1 = self.a2a(ctx, a, out=s[1])
+        o1 = self.a2a(ctx, a, out=s[1], last_use=True)      # a2b (called later) contributes to a.grad first in backward
         o2 = self.a2b(ctx, a, out=s[2])
-        d = self.d2(ctx, self.d1(ctx, x))
-        o3 = self.d3a(ctx, d, out=s[3])
+        d = self.d2(ctx, self.d1(ctx, x), last_use=True)
+        o3 = self.d3a(ctx, d, out=s[3], last_use=True)
         o4 = self.d3b(ctx, d, out=s[4])
         o5 = self.bp(ctx, self.pool(ctx, x), out=s[5])
         return concat(ctx, buf, [o0, o1, o2, o3, o4, o5])
@@ -153,7 +154,7 @@ class InceptionAux:
         self.fc = Linear(store, f"{p}.fc", 768, num_classes, trainable=True)
 
     def __call__(self, ctx, x):
-        x = self.conv1(ctx, self.conv0(ctx, self.pool(ctx, x)))
+        x = self.conv1(ctx, self.conv0(ctx, self.pool(ctx, x)), last_use=True)
         return self.fc(ctx, self.avg(ctx, x))
 
 
@@ -183,9 +184,9 @@ class Inception3:
         self.fc = Linear(store, "fc", 2048, num_classes, trainable=True)
 
     def forward(self, ctx: Context, x: Act):
-        x = self.c2b(ctx, self.c2a(ctx, self.c1a(ctx, x)))
+        x = self.c2b(ctx, self.c2a(ctx, self.c1a(ctx, x), last_use=True), last_use=True)
         x = self.mp(ctx, x)
-        x = self.c4a(ctx, self.c3b(ctx, x))
+        x = self.c4a(ctx, self.c3b(ctx, x), last_use=True)
         x = self.mp(ctx, x)
         x = self.m5d(ctx, self.m5c(ctx, self.m5b(ctx, x)))
         x = self.m6a(ctx, x)

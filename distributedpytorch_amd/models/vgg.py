@@ -33,8 +33,8 @@ class VGG:
         self.d2, self.d5 = Dropout(0.5), Dropout(0.5)
 
     def forward(self, ctx: Context, x: Act):
-        for f in self.features:
-            x = f(ctx, x)
+        for f in self.features:      # a plain chain: every conv is the sole reader of its input
+            x = f(ctx, x, last_use=True) if isinstance(f, ConvBNAct) else f(ctx, x)
         x = self.avgpool(ctx, x)
         x = self.d2(ctx, self.c0(ctx, x, relu=True))
         x = self.d5(ctx, self.c3(ctx, x, relu=True))

@@ -220,7 +220,7 @@ class Conv2d:
         if fuse is not None:
             x.bn_slab = fuse[6][:rows]
 
-    def __call__(self, ctx: Context, x: Act, relu=False, out=None) -> Act:
+    def __call__(self, ctx: Context, x: Act, relu=False, out=None, last_use=False) -> Act:
         y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
         if ctx.grad_enabled and y.needs_grad:
             def bw():
@@ -228,7 +228,7 @@ class Conv2d:
                 y.grad = None
                 if relu:
                     ops.relu_bwd(dy, y.data)
-                self.backward_raw(ctx, x, dy)
+                self.backward_raw(ctx, x, dy, last_use=last_use)
             ctx.tape.push(bw)
         return y
 
@@ -413,11 +413,18 @@ class BNAct:
         needs = x.needs_grad or bn.trainable
         y = Act(out, needs)
         if ctx.grad_enabled and needs:
+            if relu and ctx.training:
+                y.bn_src = (bn, x.data, True)        # a consumer's dgrad may do this BatchNorm's backward reduction
+
             def bw():
                 dy = y.grad
                 y.grad = None
+                slab, y.bn_slab, y.bn_src = y.bn_slab, None, None
                 dx = ctx.empty((n, h, w, c))
-                bn.backward(ctx, dy, y.data if relu else None, x.data, dx, mask_from_x=relu and ctx.training)
+                if slab is not None:
+                    _bn_backward_from_slab(bn, ctx, dy, x.data, dx, slab, m)
+                else:
+                    bn.backward(ctx, dy, y.data if relu else None, x.data, dx, mask_from_x=relu and ctx.training)
                 if x.needs_grad:
                     accumulate_grad(x, dx)
             ctx.tape.push(bw)
