@@ -169,7 +169,8 @@ def worker(args):
         net, _ = get_model(args.model, classes, device=device, dtype=dtype, small_input=small)
         opt = ArenaOptimizer(net.store, args.optimizer, lr=1e-3)
         dm = DistributedModel(net, Criterion("cross_entropy"), opt, bucket_cap_mb=args.bucket_mb,
-                              broadcast_buffers=not args.no_broadcast_buffers, native_comm=native_comm)
+                              broadcast_buffers=not args.no_broadcast_buffers, native_comm=native_comm,
+                              activation_arena=True)
         # synthetic, device-resident batch (NHWC, 3 real channels padded to the kernels' 8-channel granule)
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         x = torch.zeros(args.batch, side, side, net.in_channels, device=device, dtype=dtype)
@@ -184,6 +185,8 @@ def worker(args):
         for _ in range(args.warmup):
             step()
         fence()
+        warm_reserved = round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 1)     # includes the arena's recording step
+        torch.cuda.reset_peak_memory_stats(device)        # the reported peaks are those of the TIMED steps
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -193,6 +196,11 @@ def worker(args):
             elapsed = comm.all_reduce_scalars([elapsed], "max", device)[0]
         loss, _, _ = dm.epoch_metrics()
         peak_gb.append(round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1))
+        peak_gb.append(round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 1))
+        if dm.arena is not None and dm.arena.plans:
+            ar = list(dm.arena.summary().values())[0]
+            peak_gb.append({"peak_reserved_during_warmup_gb": warm_reserved, "arena_gb": round(ar["arena_bytes"] / 2 ** 30, 2), "live_set_gb": round(ar["live_set_lower_bound"] / 2 ** 30, 2),
+                            "requests": ar["requests"], "replayed_steps": dm.arena.stats["replayed"], "dropped": dm.arena.stats["dropped"]})
         del dm, opt, net, x, y
         torch.cuda.empty_cache()
         return elapsed, loss, use_graph
@@ -244,7 +252,9 @@ def worker(args):
                        "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb,
                        "comm": native_comm.name if native_comm is not None else "torch",
                        "fp32_mode": args.fp32_mode if args.dtype == "fp32" else None,
-                       "peak_hbm_gb": peak_gb[0] if peak_gb else None, "hipgraph": use_graph,
+                       "peak_hbm_gb": peak_gb[0] if peak_gb else None,
+                       "peak_hbm_reserved_gb": peak_gb[1] if len(peak_gb) > 1 else None,
+                       "activation_arena": peak_gb[2] if len(peak_gb) > 2 else None, "hipgraph": use_graph,
                        "mean_loss": round(loss, 4)},
             "secondary": secondary,
         }), flush=True)

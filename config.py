@@ -85,5 +85,6 @@ SYNTHETIC_DATA = _env("SYNTHETIC_DATA", False, bool)  # opt-in: when the real ID
 # RCCL/NCCL transport knobs for multi-node runs, exported by the launcher when set (the reference keeps a commented
 # NCCL_IB_DISABLE line, main.py:131): e.g. DPA_NCCL_ENV="NCCL_IB_DISABLE=1,NCCL_SOCKET_IFNAME=eth0"
 NCCL_ENV = _env("NCCL_ENV", '')
+ACTIVATION_ARENA = _env("ACTIVATION_ARENA", True, bool)   # planned activation arena (nn/arena.py): the step's tensors are views of ONE buffer at offsets planned from recorded lifetimes
 STEP_METRICS = _env("STEP_METRICS", True, bool)   # global rank 0 writes <RSL_PATH>/steps.jsonl: step, loss, acc, images/s, data ms, comm ms, phase ms (HIP events, no host sync in the loop)
 FAULT_INJECT = _env("FAULT_INJECT", '')          # test hook "rank:step": that rank exits(17) at that global step

@@ -370,11 +370,19 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
 }
 
+// Fewest tiles for which the pre-split kernel is taken (DPA_X6P_MIN_TILES, default 256).  v >= 0 sets it and returns the
+// previous value (the kernel tests set 1 so that small shapes exercise the kernel); v < 0 only reads it.
+DPA_API int dpa_x6p_min_tiles(int v) {
+  static int cur = [] { const char* e = getenv("DPA_X6P_MIN_TILES"); return e ? atoi(e) : 256; }();
+  const int prev = cur;
+  if (v >= 0) cur = v;
+  return prev;
+}
 // Can this (sub-)problem take the pre-split kernel?  (called by conv_igemm.hip's launch_tiles for fp32 in x6 mode)
 bool dpa_x6p_eligible(const ConvParams& p) {
   static const int enabled = [] { const char* e = getenv("DPA_X6P"); return (e && e[0] == '0') ? 0 : 1; }();
   static const int min_kt = [] { const char* e = getenv("DPA_X6P_MINKT"); return e ? atoi(e) : 2; }();
-  static const int min_tiles = [] { const char* e = getenv("DPA_X6P_MIN_TILES"); return e ? atoi(e) : 256; }();
+  const int min_tiles = dpa_x6p_min_tiles(-1);
   const int ntaps = p.nR * p.nS;
   // Only where its 128 x 128 (128 x 64) tiles fill the chip: skinny problems (Linear layers, small batches) need the
   // general kernel's split-K / small tiles, and dC <= 32 (DenseNet growth convs) its 128 x 32 tile.

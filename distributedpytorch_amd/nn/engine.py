@@ -294,11 +294,24 @@ class Context:
     def grad_enabled(self):
         return self.tape is not None
 
-    def empty(self, shape):
-        return torch.empty(shape, device=self.device, dtype=self.dtype)
+    def empty(self, shape, dtype=None):
+        """Step-scoped scratch / activation storage: from the planned arena when one is active (nn/arena.py)."""
+        a = _current_arena[0]
+        if a is not None:
+            return a.alloc(shape, dtype or self.dtype)
+        return torch.empty(shape, device=self.device, dtype=dtype or self.dtype)
 
     def zeros(self, shape):
         return torch.zeros(shape, device=self.device, dtype=self.dtype)
+
+
+_current_arena = [None]        # the ActivationArena serving Context.empty (set by DistributedModel around a step)
+
+
+def set_current_arena(arena):
+    prev = _current_arena[0]
+    _current_arena[0] = arena
+    return prev
 
 
 _workspaces = {}

@@ -192,7 +192,7 @@ class Conv2d:
         a = bn.aux(ctx.device)
         n, h, w, c = x.data.shape
         rows = ops.bn_reduce_rows(n * h * w, self.stride, ctx.cuda)
-        slab = torch.empty((rows, 2, c), device=ctx.device, dtype=torch.float32)
+        slab = ctx.empty((rows, 2, c), dtype=torch.float32)
         if mask_from_x:
             return (z, None, a[0], a[1], a[2], a[3], slab)
         return (z, x.data, a[0], a[1], None, None, slab)
@@ -377,7 +377,7 @@ class ConvBNReLUPool:
         needs = x.needs_grad or conv.trainable or bn.trainable
         track = ctx.grad_enabled and needs
         out = ctx.empty((n, hp, wp, cp)) if out_fn is None else out_fn(n, hp, wp)
-        idx = torch.empty((n, hp, wp, cp), device=ctx.device, dtype=torch.uint8) if track else None
+        idx = ctx.empty((n, hp, wp, cp), dtype=torch.uint8) if track else None
         ops.maxpool_fwd(z, out, idx, pool.ksize, pool.stride, pool.padding, scale=a[2], shift=a[3])
         y = Act(out, needs)
         if track:
@@ -455,7 +455,7 @@ class MaxPool2d:
         if out is None:
             out = ctx.empty((n, ho, wo, c))
         track = ctx.grad_enabled and x.needs_grad
-        idx = torch.empty((n, ho, wo, c), device=ctx.device, dtype=torch.uint8) if track else None
+        idx = ctx.empty((n, ho, wo, c), dtype=torch.uint8) if track else None
         ops.maxpool_fwd(x.data, out, idx, self.ksize, self.stride, self.padding)
         y = Act(out, x.needs_grad)
         if track:

@@ -10,7 +10,8 @@ from __future__ import annotations
 
 import torch
 
-from ..nn.engine import Tape
+from ..nn.arena import ActivationArena
+from ..nn.engine import Tape, set_current_arena
 from ..utils.trace import PhaseTimer, rng
 from ..nn.loss import Criterion
 from ..nn.optim import ArenaOptimizer
@@ -21,10 +22,14 @@ class DistributedModel:
     """The DDP-wrapped model + optimizer: owns the reducer and the device-side metric accumulators."""
 
     def __init__(self, net, criterion: Criterion, optimizer: ArenaOptimizer = None, first_bucket_mb=1.0,
-                 bucket_cap_mb=25.0, broadcast_buffers=True, sync_comm=False, native_comm=None):
+                 bucket_cap_mb=25.0, broadcast_buffers=True, sync_comm=False, native_comm=None, activation_arena=False):
+        """activation_arena: serve the step's activation / gradient tensors from a planned arena (nn/arena.py).  Opt-in
+        because it assumes that the caller keeps no tensor of a step beyond the start of the next one unless it kept
+        it in the recorded step too - true for the trainer and bench.py, not for arbitrary API users."""
         self.net, self.criterion, self.opt = net, criterion, optimizer
         dev = net.store.device
         self.device = dev
+        self.arena = ActivationArena(dev) if activation_arena else None
         self.reducer = None
         if optimizer is not None:
             self.reducer = GradReducer(net.store, optimizer, first_bucket_mb, bucket_cap_mb, broadcast_buffers,
@@ -62,11 +67,15 @@ class DistributedModel:
         tape = Tape()
         tape.param_ready_hook = red.param_ready
         red.begin_backward()
-        with rng("forward+loss"):
-            self._forward_loss(x, labels, tape)
-        mark("fwd")
-        with rng("backward+allreduce"):
-            tape.backward()
+        prev = self._arena_begin(("train", tuple(x.shape), x.dtype))
+        try:
+            with rng("forward+loss"):
+                self._forward_loss(x, labels, tape)
+            mark("fwd")
+            with rng("backward+allreduce"):
+                tape.backward()
+        finally:
+            self._arena_end(prev)
         mark("bwd")
         with rng("wait+optimizer"):
             red.finish_and_step()
@@ -102,7 +111,22 @@ class DistributedModel:
             if self.reducer is not None:
                 self.reducer.sync_buffers()
             self._need_buffer_sync = False
-        self._forward_loss(x, labels, None)
+        prev = self._arena_begin(("eval", tuple(x.shape), x.dtype))
+        try:
+            self._forward_loss(x, labels, None)
+        finally:
+            self._arena_end(prev)
+
+    def _arena_begin(self, key):
+        if self.arena is None:
+            return None
+        self.arena.begin(key)
+        return (set_current_arena(self.arena),)
+
+    def _arena_end(self, prev):
+        if prev is not None:
+            self.arena.end()
+            set_current_arena(prev[0])
 
     # ------------------------------------------------------------------ hipGraph iteration (single-rank body)
     def capture_train_step(self, x, labels, warmup=3):

@@ -158,7 +158,8 @@ def _build(args, gpu, rank, modelName, cfg, with_optimizer):
     dmodel = DistributedModel(net, criterion, optimizer, first_bucket_mb=getattr(cfg, "FIRST_BUCKET_MB", 1.0),
                               bucket_cap_mb=getattr(cfg, "BUCKET_CAP_MB", 25.0),
                               broadcast_buffers=getattr(cfg, "BROADCAST_BUFFERS", True),
-                              sync_comm=getattr(cfg, "SYNC_COMM", False), native_comm=_NATIVE[-1] if _NATIVE else None)
+                              sync_comm=getattr(cfg, "SYNC_COMM", False), native_comm=_NATIVE[-1] if _NATIVE else None,
+                              activation_arena=getattr(cfg, "ACTIVATION_ARENA", True))
     from .utils.steplog import StepLog
     dmodel.steplog = StepLog(os.path.join(cfg.RSL_PATH, "steps.jsonl"), device, args.worldSize, args.batchSize,
                              enabled=with_optimizer and rank == 0 and getattr(cfg, "STEP_METRICS", True))

@@ -409,3 +409,71 @@ def test_fp32_mode_switch_roundtrip():
             native.set_fp32_mode("tf32")
     finally:
         native.set_fp32_mode(prev)
+
+
+def test_activation_arena_plan_replay_and_bitwise_training():
+    """nn/arena.py: the planner never overlaps live buffers, replayed steps are bit-identical to allocator-served steps,
+    verify mode accepts a reproducible step, and a step that deviates from the recording drops its plan."""
+    import ctypes
+    import random
+    from distributedpytorch_amd.models.factory import get_model
+    from distributedpytorch_amd.nn.loss import Criterion
+    from distributedpytorch_amd.nn.optim import ArenaOptimizer
+    from distributedpytorch_amd.ops import native
+    from distributedpytorch_amd.parallel.ddp import DistributedModel
+    # --- the C++ planner on random lifetimes
+    lib = native.host_lib()
+    lib.dpa_plan_arena.restype = ctypes.c_longlong
+    rnd = random.Random(3)
+    n = 300
+    arr = ctypes.c_longlong * n
+    size, start, end, off = arr(), arr(), arr(), arr()
+    for i in range(n):
+        size[i], start[i], end[i] = rnd.randint(1, 5000), i, i + rnd.randint(1, 60)
+    lb = ctypes.c_longlong(0)
+    peak = lib.dpa_plan_arena(n, size, start, end, ctypes.c_longlong(256), off, ctypes.byref(lb))
+    assert peak >= lb.value > 0 and peak <= 1.3 * lb.value
+    for i in range(n):
+        assert off[i] % 256 == 0 and off[i] + size[i] <= peak
+        for j in range(i):
+            if start[j] < end[i] and start[i] < end[j]:
+                assert off[i] + size[i] <= off[j] or off[j] + size[j] <= off[i], (i, j)
+
+    # --- training with and without the arena: identical parameters after 4 steps
+    def run(arena, env=None):
+        for k, v in (env or {}).items():
+            os.environ[k] = v
+        try:
+            torch.manual_seed(0)
+            net, _ = get_model("resnet", 10, device="cpu", dtype=torch.float32)
+            dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3), activation_arena=arena)
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn(2, 32, 32, net.in_channels, generator=g)
+            y = torch.randint(0, 10, (2,), generator=g)
+            for _ in range(4):
+                dm.train_step(x, y)
+            dm.eval_step(x, y)
+            dm.train_step(x, y)
+            return net.store.p.clone(), dm
+        finally:
+            for k in (env or {}):
+                os.environ.pop(k, None)
+    p0, _ = run(False)
+    p1, dm = run(True)
+    assert torch.equal(p0, p1)
+    st = dm.arena.stats
+    assert st["recorded"] == 2 and st["replayed"] >= 3 and st["dropped"] == 0, st       # one recording per step kind
+    summ = dm.arena.summary()
+    train = [v for k, v in summ.items() if "train" in k][0]
+    assert train["in_arena"] > 50 and train["arena_bytes"] <= 1.15 * train["live_set_lower_bound"], train
+    p2, dm2 = run(True, {"DPA_ACT_ARENA_VERIFY": "1"})          # every step re-recorded and compared with the plan
+    assert torch.equal(p0, p2) and dm2.arena.stats["replayed"] == 0
+    # --- a different batch shape is another key; a request that deviates from the recording drops the plan
+    x2 = torch.randn(3, 32, 32, dm.net.in_channels)
+    dm.train_step(x2, torch.randint(0, 10, (3,)))
+    assert len(dm.arena.plans) == 3 or dm.arena.stats["recorded"] >= 2
+    a = dm.arena
+    key = next(k for k in a.plans if k[0] == "train" and k[1][0] == 2)
+    a.begin(key)
+    t = a.alloc((7, 7), torch.float32)                          # not what the recorded step asked for first
+    assert t.shape == (7, 7) and key not in a.plans and a.stats["dropped"] == 1
