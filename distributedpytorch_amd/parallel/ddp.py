@@ -138,6 +138,10 @@ class DistributedModel:
         waits) cannot be captured."""
         if not self.can_capture():
             return False
+        if self.arena is not None:
+            # a captured graph owns a static pool of its own: recording / replaying the arena during the warm-up would
+            # only leave a second copy of the activation footprint allocated next to it
+            self.arena.enabled = False
         self._static_x, self._static_y = x.clone(), labels.clone()
         # warm-up iterations must not perturb training: snapshot every piece of mutable state and restore it
         st, opt = self.net.store, self.opt
