@@ -40,10 +40,14 @@ for (h, ci, co, k, s, p, cnt) in LAYERS:
     dx = torch.empty_like(x)
     dw = torch.empty(co, k, k, ci, device="cuda")
     ws = torch.empty(H.wgrad_workspace_numel(co, k * k * ci), device="cuda")
-    stats = torch.empty(H.stats_rows(N * ho * ho, co, dt), 2, co, device="cuda")
+    stats = torch.empty((N * ho * ho + 63) // 64, 2, co, device="cuda")
+    w3 = wt3 = None
+    if dt == torch.float32 and ci % 32 == 0 and co % 32 == 0:      # the pre-split planes the training step passes in x6 mode
+        w3 = H.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
+        wt3 = H.split3_planes(wt, torch.empty(3 * wt.numel(), device="cuda", dtype=torch.bfloat16))
     fl = 2.0 * N * ho * ho * co * k * k * ci
-    tf = timeit(lambda: H.conv_fprop(x, w, y, (s, s), (p, p), stats=stats))
-    td = timeit(lambda: H.conv_dgrad(dy, wt, dx, (s, s), (p, p)))
+    tf = timeit(lambda: H.conv_fprop(x, w, y, (s, s), (p, p), stats=stats, w3=w3))
+    td = timeit(lambda: H.conv_dgrad(dy, wt, dx, (s, s), (p, p), wt3=wt3))
     tw = timeit(lambda: H.conv_wgrad(dy, x, dw, (k, k), (s, s), (p, p), workspace=ws))
     tot["fprop"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
     print(f"{name:34s} {fl/1e9:8.1f} | {tf*1e6:9.1f} {fl/tf/1e12:6.0f} | {td*1e6:9.1f} {fl/td/1e12:6.0f} | {tw*1e6:9.1f} {fl/tw/1e12:6.0f}   x{cnt}")
