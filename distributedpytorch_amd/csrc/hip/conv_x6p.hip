@@ -80,13 +80,18 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
   const int row0 = tid >> 3;
   const int ck = (tid & 7) ^ ((row0 >> 1) & 7);
   const int ntaps = p.nR * p.nS;
+  // (block-uniform) the short-reduction 1x1 layers spend as long in this prologue as in their two K-tiles
+  const bool linear = ntaps == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.sH == p.dH && p.sW == p.dW;
   long long a_rowoff[A_PASSES];
   uint32_t a_mask[A_PASSES];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + row0 + RPP * i;
     a_mask[i] = 0; a_rowoff[i] = 0;
-    if (m < p.M) {
+    if (m < p.M && linear) {        // 1x1, stride 1, no padding: GEMM row m IS source pixel m, its single tap always valid
+      a_rowoff[i] = (long long)m * p.s_cs + p.s_co + ck * 4;
+      a_mask[i] = 1u;
+    } else if (m < p.M) {
       const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
       const int xo = m - (int)t1 * p.cls_nw;
       const uint32_t img = fd_div(t1, p.fd_nH);
