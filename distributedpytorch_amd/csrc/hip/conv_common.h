@@ -60,6 +60,10 @@ struct ConvParams {
   // timing is representative.  Not used by the framework.
   const float* nol_scale;
   const float* nol_shift;
+  // EXPERIMENT (scripts/bench_x6pp.py, docs/KERNELS.md §2): the ACTIVATION operand pre-split into three bf16 planes as well
+  // ("producer-side split"): [3][sN*sH*sW*s_cs] bf16.  The x6p kernel then has no VALU split at all.  Not used by the framework.
+  const void* src3;
+  long long src3_plane;
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;

@@ -57,10 +57,11 @@ DPA_API int dpa_split3_planes(const float* w, void* out, long long n, hipStream_
 
 // NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
 // 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
-template <int TN, bool DGRAD, int NW, int MF, bool NOL = false>
+template <int TN, bool DGRAD, int NW, int MF, bool NOL = false, bool APL = false>
 __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p) {
   constexpr int BM = 32 * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
-  constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
+  constexpr int AP_BYTES = BM * 64;                // one plane of the activation tile (APL: experiment, see ConvParams::src3)
+  constexpr int A_BYTES = APL ? 3 * AP_BYTES : BM * 128, BP_BYTES = BN * 64;
   constexpr int STAGE_BYTES = A_BYTES + 3 * BP_BYTES;
   constexpr int RPP = NT / 8;                      // rows staged per pass (8 threads per 128-byte row)
   constexpr int A_PASSES = BM / RPP;               // = 4
@@ -109,6 +110,40 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
       a_mask[i] = mk;
     }
   }
+  // ---- APL: the activation tile as three planes, staged in 1-KiB pieces exactly like the filter planes -----------------
+  constexpr int AP_PIECES = APL ? (3 * (BM / 16)) / NW : 1;
+  long long ap_off[AP_PIECES];
+  uint32_t ap_mask[AP_PIECES];
+  int ap_lds[AP_PIECES];
+  if constexpr (APL) {
+#pragma unroll
+    for (int i = 0; i < AP_PIECES; ++i) {
+      const int q = wave + NW * i;
+      const int plane = q / (BM / 16), r16 = q - plane * (BM / 16);
+      const int row = 16 * r16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((-(row >> 2)) & 3);
+      const int m = m0 + row;
+      ap_mask[i] = 0; ap_off[i] = 0;
+      ap_lds[i] = plane * AP_BYTES + r16 * 1024;
+      if (m < p.M) {
+        const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+        const int xo = m - (int)t1 * p.cls_nw;
+        const uint32_t img = fd_div(t1, p.fd_nH);
+        const int yo = (int)t1 - (int)img * p.cls_nh;
+        const int y0 = DGRAD ? yo + p.base_y : yo * p.sh - p.ph;
+        const int x0 = DGRAD ? xo + p.base_x : xo * p.sw - p.pw;
+        ap_off[i] = (long long)plane * p.src3_plane + ((long long)img * (p.sH * p.sW) + (long long)y0 * p.sW + x0) * p.s_cs + p.s_co + chunk * 8;
+        uint32_t mk = 0;
+        for (int t = 0; t < ntaps; ++t) {
+          const int r = (int)fd_div((uint32_t)t, p.fd_nS), s_ = t - r * p.nS;
+          const int sy = DGRAD ? y0 - r : y0 + r;
+          const int sx = DGRAD ? x0 - s_ : x0 + s_;
+          if (((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW)) mk |= 1u << t;
+        }
+        ap_mask[i] = mk;
+      }
+    }
+  }
   // ---- B operand: piece q = wave + NW i of the K-tile: plane q / TN, rows 16 (q % TN) .. + 15; lane -> row lane >> 2,
   //      slot lane & 3, which holds logical chunk slot ^ ((-(row >> 2)) & 3) -----------------------------------------------
   long long b_off[B_PIECES];
@@ -138,10 +173,19 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
     const int woff = DGRAD ? (((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + cbase) : (int)k0;
     const uint32_t bit = 1u << tap;
     char* stage = smem + buf * STAGE_BYTES;
+    if constexpr (APL) {
+      const bf16_t* src3 = reinterpret_cast<const bf16_t*>(p.src3);
+#pragma unroll
+      for (int i = 0; i < AP_PIECES; ++i) {
+        const void* pa = (ap_mask[i] & bit) ? (const void*)(src3 + (ap_off[i] + delta)) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds((gbl_void*)pa, (lds_void*)(stage + ap_lds[i]), 16, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const float* pa = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
       __builtin_amdgcn_global_load_lds((gbl_void*)pa, (lds_void*)(stage + (i * RPP + wave * 8) * 128), 16, 0, 0);
+    }
     }
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i)
@@ -276,11 +320,20 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
       const char* tA = smem + (kt & 1) * STAGE_BYTES;
       const char* tB = tA + A_BYTES;
       uint4 fa[2][TM];
+      uint4 ap[TM][3];
+      if constexpr (APL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            ap[i][part] = *reinterpret_cast<const uint4*>(tA + part * AP_BYTES + (wave * 32 + i * 16) * 64 + b_frag);
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * 32 + i * 16 + fr, 2 * fq + ks));
+      }
       uint4 bp[JH][3];
 #pragma unroll
       for (int j = 0; j < JH; ++j)
@@ -301,9 +354,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
           hi.z = __float_as_uint(fmaxf(__uint_as_float(hi.z) * s1.z + h1.z, 0.f)); hi.w = __float_as_uint(fmaxf(__uint_as_float(hi.w) * s1.w + h1.w, 0.f));
         }
       }
-      uint4 ap[TM][3];
+      if constexpr (!APL) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
+        for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -403,6 +457,10 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
   if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF>), grid, block, lds, s, p);
+  else if (p.src3) {
+    const size_t lds3 = (size_t)2 * (3 * BM * 64 + 3 * BN * 64);
+    hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, false, true>), grid, block, lds3 > epi ? lds3 : epi, s, p);
+  }
   else if (p.nol_scale) hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, true>), grid, block, lds, s, p);
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
 }
@@ -430,7 +488,8 @@ bool dpa_x6p_eligible(const ConvParams& p) {
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   p.m_off = 0; p.stats_row0 = 0;
-  if (p.dC <= 64) x6p_launch<4, 4, 16>(p, dgrad, s);
-  else            x6p_launch<8, 4, 16>(p, dgrad, s);
+  static const int apl_tn = [] { const char* e = getenv("DPA_X6PP_TN"); return e ? atoi(e) : 8; }();      // experiment: tile width with src3
+  if (p.dC <= 64 || (p.src3 && apl_tn == 4)) x6p_launch<4, 4, 16>(p, dgrad, s);
+  else                                       x6p_launch<8, 4, 16>(p, dgrad, s);
   return p.tilesM;
 }
