@@ -1,4 +1,5 @@
-"""Short-K 1x1 layers of ResNet-50 (memory-bound) under the persistent-block / phase-offset switches of conv_x6p.hip."""
+"""Forward time of the short-reduction 1x1 layers of ResNet-50 (and two 3x3 layers for contrast) through the pre-split
+fp32 kernel - the harness behind the short-K paragraph of docs/KERNELS.md §2."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from distributedpytorch_amd.ops import hip_conv as H
@@ -18,4 +19,4 @@ for hw, ci, co, k in ((56, 64, 256, 1), (56, 256, 64, 1), (28, 128, 512, 1), (28
     y = torch.empty(N, hw, hw, co, device="cuda")
     w3 = H.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
     out.append(f"{hw}x{hw} {ci}->{co} k{k}: {timeit(lambda: H.conv_fprop(x, w, y, (1, 1), (k // 2, k // 2), w3=w3)):.0f}")
-print(f"persist={os.environ.get('DPA_X6P_PERSIST')} delay={os.environ.get('DPA_X6P_DELAY')} | " + " | ".join(out))
+print("us: " + " | ".join(out))
