@@ -31,6 +31,8 @@ def main():
     a = ap.parse_args()
     world, rank, lr = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     cuda = torch.cuda.is_available()
+    if cuda and os.environ.get("DPA_SHARE_GPU", "0") == "1":      # rehearsal: several ranks on one GPU (DPA_COMM_TRANSPORT=tcp)
+        lr = lr % torch.cuda.device_count()
     dev = torch.device("cuda", lr) if cuda else torch.device("cpu")
     if cuda:
         torch.cuda.set_device(lr)
