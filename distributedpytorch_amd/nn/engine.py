@@ -318,12 +318,14 @@ _workspaces = {}
 
 
 _side_streams = {}
-# DPA_BWD_STREAMS=2: weight-gradient kernels on a second stream.  Joining right after the layer's own dgrad gained
-# nothing (+0.7 % fp32, +0 % bf16: two MFMA-bound kernels share the matrix pipes).  With the join DEFERRED by
-# DPA_BWD_LAG layers (nn/layers.py: Conv2d.backward_raw) the wgrad of layer k also overlaps the memory-bound
-# BatchNorm-backward kernels of the layers below it.
-DUAL_STREAM_BACKWARD = os.environ.get("DPA_BWD_STREAMS", "1") == "2"
-BWD_LAG = int(os.environ.get("DPA_BWD_LAG", "2"))
+# Weight-gradient kernels run on a second stream (DPA_BWD_STREAMS=1 puts them back on the main stream) and the main stream
+# joins them DPA_BWD_LAG conv layers later (nn/layers.py: Conv2d.backward_raw).  With lag 1 the wgrad of layer k overlaps
+# the small dependent kernels of the layer below it (slab reduce -> BatchNorm finalize -> dx: ~40 us per layer in which a
+# single stream leaves the GPU nearly idle): -1 % on the ResNet-50 step, measured A/B on one box (214.0 vs 216.3 ms).
+# Larger lags gain nothing (two MFMA-bound kernels share the matrix pipes; the memory-bound BatchNorm kernels do not get
+# co-scheduled with a kernel that fills VGPRs and LDS).
+DUAL_STREAM_BACKWARD = os.environ.get("DPA_BWD_STREAMS", "2") == "2"
+BWD_LAG = int(os.environ.get("DPA_BWD_LAG", "1"))
 
 
 def side_stream(device):
@@ -335,7 +337,7 @@ def side_stream(device):
     key = str(device)
     s = _side_streams.get(key)
     if s is None:
-        s = _side_streams[key] = torch.cuda.Stream(device=device)      # priority 0: see csrc/comm/rccl_comm.cpp
+        s = _side_streams[key] = torch.cuda.Stream(device=device)      # priority 0, like the comm stream: csrc/comm/rccl_backend.cpp
     return s
 
 
