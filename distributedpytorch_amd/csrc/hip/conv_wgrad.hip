@@ -30,6 +30,26 @@ template <typename T> struct WgLds;
 template <> struct WgLds<bf16_t> { static constexpr int PAD = 32; };   // bytes; shifts each pixel row by 8 banks
 template <> struct WgLds<float>  { static constexpr int PAD = 64; };   // (pitch/4) % 32 == 16
 
+// Bank swizzle of the bf16-plane tiles read with ds_read_b64_tr_b16 (x6 path, tile rows of 256 or 512 bytes = 128 / 256
+// columns).  LDS serves 32 lanes x 8 bytes per pass over 64 banks x 4 bytes.  The padded layout (pitch 288 bytes) had
+//   * transposed reads: a 16-lane group addresses 4 pixel rows x 32 bytes, and the second group of the pass sits 8 rows
+//     further - 8 x 288 bytes is a multiple of the 256-byte bank line, so both groups hit the same banks;
+//   * B-operand stores: a pass writes 4 consecutive rows x 64 bytes whose bank ranges overlap pairwise at that pitch
+//   (PMC: SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE).  Now: pitch = the row width (every row starts at bank 0) and
+// the 32-byte block index inside a row is XOR-ed with swz(row) = 2 * (row & 3) | (row >> 3 & 1).  A transposed read then
+// touches blocks blk ^ {0, 2, 4, 6} ^ {0, 1} - eight distinct 8-bank groups; a B store pass touches block pairs
+// (2i ^ s, 2i + 1 ^ s) for s = 0, 2, 4, 6 - four distinct pairs; an A store pass is one full row.  Fragments (32 bytes)
+// and store chunks (8 bytes) never straddle a block.  Writers and readers both go through tr_off().
+template <int ROW_BYTES>
+struct TrTile {
+  static constexpr bool SWZ = ROW_BYTES == 256 || ROW_BYTES == 512;
+  static constexpr int PITCH = SWZ ? ROW_BYTES : ROW_BYTES + WgLds<bf16_t>::PAD;
+  static __device__ __forceinline__ int off(int row, int byte_in_row) {
+    if constexpr (SWZ) return row * PITCH + (byte_in_row ^ ((((row & 3) << 1) | ((row >> 3) & 1)) << 5));
+    else return row * PITCH + byte_in_row;
+  }
+};
+
 // X6 (fp32 operands only): the staging threads split every value into three bf16 planes (conv_common.h, split3_pair)
 // on the way into LDS - once per element - and the K loop runs the bf16 fragment path on the six plane pairs.
 template <typename T, int WM, int WN, int TM, int TN, bool X6 = false>
@@ -39,8 +59,13 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
   constexpr int BKP = 8 * VEC;                          // pixels per K-tile (64 bf16 / 32 fp32)
   constexpr int ESZ = X6 ? 2 : (int)sizeof(T);          // bytes per element in LDS
   constexpr int LPAD = X6 ? WgLds<bf16_t>::PAD : WgLds<T>::PAD;
-  constexpr int PITCH_A = BM * ESZ + LPAD;
-  constexpr int PITCH_B = BN * ESZ + LPAD;
+  typedef TrTile<BM * 2> TA;                          // x6 plane tiles (bank-swizzled where the row width allows)
+  typedef TrTile<BN * 2> TB;
+  // (the native bf16 path keeps the padded layout: the swizzle measured +1.2 ms per bf16 ResNet-50 step there - its
+  //  16-byte stores and 64-row tiles behave differently - and -2.6 ms per fp32 step on the x6 planes)
+  constexpr bool TR = X6;
+  constexpr int PITCH_A = TR ? TA::PITCH : BM * ESZ + LPAD;
+  constexpr int PITCH_B = TR ? TB::PITCH : BN * ESZ + LPAD;
   constexpr int PLANE_A = BKP * PITCH_A, PLANE_B = BKP * PITCH_B;   // X6: three planes per operand
   constexpr int CPR_A = BM / VEC, CPR_B = BN / VEC;     // 16-byte chunks per pixel row
   constexpr int A_PASSES = BKP * CPR_A / 256;
@@ -130,7 +155,7 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
         split3_pair(__uint_as_float(ra[i].z), __uint_as_float(ra[i].w), hi);
 #pragma unroll
         for (int part = 0; part < 3; ++part)
-          *reinterpret_cast<uint2*>(ldsA + part * PLANE_A + (ra0 + RPP_A * i) * PITCH_A + ca * 8) = make_uint2(lo[part], hi[part]);
+          *reinterpret_cast<uint2*>(ldsA + part * PLANE_A + TA::off(ra0 + RPP_A * i, ca * 8)) = make_uint2(lo[part], hi[part]);
       }
 #pragma unroll
       for (int i = 0; i < B_CHUNKS; ++i) {
@@ -139,16 +164,16 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
         split3_pair(__uint_as_float(rb[i].z), __uint_as_float(rb[i].w), hi);
 #pragma unroll
         for (int part = 0; part < 3; ++part)
-          *reinterpret_cast<uint2*>(ldsB + part * PLANE_B + brow * PITCH_B + (bsub + TPR * i) * 8) = make_uint2(lo[part], hi[part]);
+          *reinterpret_cast<uint2*>(ldsB + part * PLANE_B + TB::off(brow, (bsub + TPR * i) * 8)) = make_uint2(lo[part], hi[part]);
       }
       return;
     }
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
-      *reinterpret_cast<uint4*>(ldsA + (ra0 + RPP_A * i) * PITCH_A + ca * 16) = ra[i];
+      *reinterpret_cast<uint4*>(ldsA + (TR ? TA::off(ra0 + RPP_A * i, ca * 16) : (ra0 + RPP_A * i) * PITCH_A + ca * 16)) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i)
-      *reinterpret_cast<uint4*>(ldsB + brow * PITCH_B + (bsub + TPR * i) * 16) = rb[i];
+      *reinterpret_cast<uint4*>(ldsB + (TR ? TB::off(brow, (bsub + TPR * i) * 16) : brow * PITCH_B + (bsub + TPR * i) * 16)) = rb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -175,9 +200,10 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int part = 0; part < 3; ++part) {
-            const char* base = ldsB + part * PLANE_B + krow * PITCH_B + (wn * TN * 16 + j * 16 + 4 * pp) * 2;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base + 4 * PITCH_B));
+            const char* pl = ldsB + part * PLANE_B;
+            const int cb = (wn * TN * 16 + j * 16 + 4 * pp) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TB::off(krow, cb)));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TB::off(krow + 4, cb)));
             fb[j][part] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
@@ -185,9 +211,10 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
           bf16x8 fa[3];
 #pragma unroll
           for (int part = 0; part < 3; ++part) {
-            const char* base = ldsA + part * PLANE_A + krow * PITCH_A + (wm * TM * 16 + i * 16 + 4 * pp) * 2;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(base + 4 * PITCH_A));
+            const char* pl = ldsA + part * PLANE_A;
+            const int cb = (wm * TM * 16 + i * 16 + 4 * pp) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TA::off(krow, cb)));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TA::off(krow + 4, cb)));
             fa[part] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
@@ -326,7 +353,7 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   p.out = split == 1 ? grad : workspace;
   if (x6) {
     if constexpr (sizeof(T) == 4) {
-      const size_t lds = (size_t)BKP * 3 * ((BM + BN) * 2 + 2 * WgLds<bf16_t>::PAD);
+      const size_t lds = (size_t)BKP * 3 * (TrTile<BM * 2>::PITCH + TrTile<BN * 2>::PITCH);
       hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN, true>), dim3(tiles * split), dim3(256), lds, s, p);
     }
   } else {
