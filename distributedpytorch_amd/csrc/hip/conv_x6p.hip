@@ -465,13 +465,24 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
 }
 
-// Fewest tiles for which the pre-split kernel is taken (DPA_X6P_MIN_TILES, default 256).  v >= 0 sets it and returns the
+// Fewest tiles for which the pre-split kernel is taken (DPA_X6P_MIN_TILES, default 96: profiles/r2_x6p_small_batch_sweep.txt).  v >= 0 sets it and returns the
 // previous value (the kernel tests set 1 so that small shapes exercise the kernel); v < 0 only reads it.
 DPA_API int dpa_x6p_min_tiles(int v) {
-  static int cur = [] { const char* e = getenv("DPA_X6P_MIN_TILES"); return e ? atoi(e) : 256; }();
+  static int cur = [] { const char* e = getenv("DPA_X6P_MIN_TILES"); return e ? atoi(e) : 96; }();
   const int prev = cur;
   if (v >= 0) cur = v;
   return prev;
+}
+// Tile width: 128 columns, or 64 for dC <= 64 and for problems whose 128-column tiles would not fill one round of the
+// chip's 512 block slots (small batches: twice the blocks at half the filter reuse).  DPA_X6P_NARROW_BELOW (tiles,
+// default 512).  Measured on the batch-64 zoo (the reference's default batch): ResNet-18 +9.7 %, AlexNet +5 %,
+// Inception-v3 +6.6 %, the others unchanged; nothing in the batch-1024 ResNet-50 step is below 512 tiles.
+static long long x6p_tiles(const ConvParams& p, bool narrow) {
+  return (long long)((p.M + 127) / 128) * ((p.dC + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
+}
+static bool x6p_narrow(const ConvParams& p) {
+  static const int below = [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }();
+  return p.dC <= 64 || x6p_tiles(p, false) < below;
 }
 // Can this (sub-)problem take the pre-split kernel?  (called by conv_igemm.hip's launch_tiles for fp32 in x6 mode)
 bool dpa_x6p_eligible(const ConvParams& p) {
@@ -481,15 +492,14 @@ bool dpa_x6p_eligible(const ConvParams& p) {
   const int ntaps = p.nR * p.nS;
   // Only where its 128 x 128 (128 x 64) tiles fill the chip: skinny problems (Linear layers, small batches) need the
   // general kernel's split-K / small tiles, and dC <= 32 (DenseNet growth convs) its 128 x 32 tile.
-  const long long tiles = (long long)((p.M + 127) / 128) * ((p.dC + (p.dC <= 64 ? 63 : 127)) / (p.dC <= 64 ? 64 : 128));
   return enabled && p.wgt3 && (p.sC % 32 == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni && p.Kg >= 32 * min_kt && p.dC > 32 &&
-         tiles >= min_tiles;
+         x6p_tiles(p, x6p_narrow(p)) >= min_tiles;
 }
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   p.m_off = 0; p.stats_row0 = 0;
   static const int apl_tn = [] { const char* e = getenv("DPA_X6PP_TN"); return e ? atoi(e) : 8; }();      // experiment: tile width with src3
-  if (p.dC <= 64 || (p.src3 && apl_tn == 4)) x6p_launch<4, 4, 16>(p, dgrad, s);
+  if (x6p_narrow(p) || (p.src3 && apl_tn == 4)) x6p_launch<4, 4, 16>(p, dgrad, s);
   else                                       x6p_launch<8, 4, 16>(p, dgrad, s);
   return p.tilesM;
 }

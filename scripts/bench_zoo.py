@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--models", default="resnet,alexnet,vgg,squeezenet,densenet,inception")
 ap.add_argument("--no-torch", action="store_true")
+ap.add_argument("--fp32-only", action="store_true", help="only the default fp32 eager number (knob sweeps)")
 a = ap.parse_args()
 
 def timeit(step, n):
@@ -57,6 +58,10 @@ def torch_eager(name):
 for name in a.models.split(","):
     rec = {"model": name, "batch": a.batch}
     rec["engine_fp32"] = round(engine(name, torch.float32, False), 1)
+    if a.fp32_only:
+        print(json.dumps(rec), flush=True)
+        torch.cuda.empty_cache()
+        continue
     rec["engine_fp32_graph"] = round(engine(name, torch.float32, True), 1)
     from distributedpytorch_amd.ops.native import set_fp32_mode
     prev = set_fp32_mode("x6")          # fp32 products on the bf16 matrix pipe (opt-in mode)
