@@ -17,6 +17,9 @@ from .. import ops
 from .engine import BWD_LAG, Act, Context, ParamStore, accumulate_grad, pad_to, side_stream, workspace
 
 
+# fewest GFLOP of a weight gradient that is worth the side stream's fork / join events (profiles/r2_side_stream_threshold.txt)
+SIDE_MIN_GFLOP = float(os.environ.get("DPA_BWD_SIDE_MIN_GFLOP", "40"))
+
 # DPA_FUSE_BN_BWD=0: never fuse the BatchNorm-backward reduction into the dgrad epilogue (A/B switch)
 _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
 
@@ -129,6 +132,12 @@ class Conv2d:
         pass) - it may then finish x's gradient for the BatchNorm that produced x (see _dgrad)."""
         st = self.store
         side = side_stream(ctx.device) if (self.trainable and x.needs_grad) else None
+        if side is not None and SIDE_MIN_GFLOP > 0.0:
+            # the fork / join events cost more than the overlap gains when the kernels are small (batch 64: DenseNet -23 %,
+            # AlexNet -8 % with the fork on every layer): only weight gradients above a FLOP count take the side stream
+            gflop = 2e-9 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * self.ksize[0] * self.ksize[1] * x.data.shape[3]
+            if gflop < SIDE_MIN_GFLOP:
+                side = None
         if side is not None:
             # fork: wgrad on the side stream, dgrad (and everything after it) on the main stream.  The join is deferred:
             # the main stream waits for this wgrad only BWD_LAG conv layers further down the tape (or at the end of

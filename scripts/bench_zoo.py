@@ -26,7 +26,7 @@ def timeit(step, n):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 
 def engine(name, dtype, graph):
-    side = get_model_input_size(name)
+    side = 224 if name == 'resnet50' else get_model_input_size(name)
     net, _ = get_model(name, 10, device="cuda", dtype=dtype)
     dm = DistributedModel(net, Criterion(), ArenaOptimizer(net.store, "adam", lr=1e-3))
     x = torch.zeros(a.batch, side, side, net.in_channels, device="cuda", dtype=dtype)
