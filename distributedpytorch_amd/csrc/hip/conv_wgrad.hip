@@ -52,8 +52,11 @@ struct TrTile {
 
 // X6 (fp32 operands only): the staging threads split every value into three bf16 planes (conv_common.h, split3_pair)
 // on the way into LDS - once per element - and the K loop runs the bf16 fragment path on the six plane pairs.
+// Resident blocks per CU the register budget is set for: 3, or 2 for x6 (plane splits) and for the bf16 64 x 256 tile (at
+// 3 it spilled 26 VGPRs to scratch: stem wgrad -24 %, 56x56 256->64 -9 % at 2).
+#define WG_MINB(T, WN, TN, X6) ((X6 || (sizeof(T) == 2 && WN == 4 && TN == 4)) ? 2 : 3)
 template <typename T, int WM, int WN, int TM, int TN, bool X6 = false>
-__global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel(const WgradParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BKP = 8 * VEC;                          // pixels per K-tile (64 bf16 / 32 fp32)
@@ -61,9 +64,9 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
   constexpr int LPAD = X6 ? WgLds<bf16_t>::PAD : WgLds<T>::PAD;
   typedef TrTile<BM * 2> TA;                          // x6 plane tiles (bank-swizzled where the row width allows)
   typedef TrTile<BN * 2> TB;
-  // (the native bf16 path keeps the padded layout: the swizzle measured +1.2 ms per bf16 ResNet-50 step there - its
-  //  16-byte stores and 64-row tiles behave differently - and -2.6 ms per fp32 step on the x6 planes)
-  constexpr bool TR = X6;
+  // native bf16: swizzled only for the 128 x 128 tile (-5..-10 % on those layers, PMC: 43 % -> 0 conflict cycles); the
+  // 64 x 256 instance is at its register limit and the per-store XOR addresses push it into scratch (+50 % time)
+  constexpr bool TR = X6 || (sizeof(T) == 2 && BM == 128 && BN == 128);
   constexpr int PITCH_A = TR ? TA::PITCH : BM * ESZ + LPAD;
   constexpr int PITCH_B = TR ? TB::PITCH : BN * ESZ + LPAD;
   constexpr int PLANE_A = BKP * PITCH_A, PLANE_B = BKP * PITCH_B;   // X6: three planes per operand
@@ -235,16 +238,16 @@ __global__ void __launch_bounds__(256, (X6 ? 2 : 3)) conv_wgrad_kernel(const Wgr
           for (int i = 0; i < TM; ++i) {
             const int col = (wm * TM * 16 + i * 16 + 4 * pp) * 2;
             const int krow = ks * 32 + 8 * fq + q;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsA + krow * PITCH_A + col));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsA + (krow + 4) * PITCH_A + col));
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsA + (TR ? TA::off(krow, col) : krow * PITCH_A + col)));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsA + (TR ? TA::off(krow + 4, col) : (krow + 4) * PITCH_A + col)));
             fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int col = (wn * TN * 16 + j * 16 + 4 * pp) * 2;
             const int krow = ks * 32 + 8 * fq + q;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsB + krow * PITCH_B + col));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsB + (krow + 4) * PITCH_B + col));
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsB + (TR ? TB::off(krow, col) : krow * PITCH_B + col)));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ldsB + (TR ? TB::off(krow + 4, col) : (krow + 4) * PITCH_B + col)));
             fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
@@ -337,7 +340,7 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   // residency.)  Slab traffic grows with the split.
   static const int target_env = [] { const char* e = getenv("DPA_WGRAD_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
   const bool x6 = sizeof(T) == 4 && dpa_get_fp32_mode() == 1;
-  const int target = target_env ? target_env : (x6 ? 512 : 768);
+  const int target = target_env ? target_env : ((x6 || WG_MINB(T, WN, TN, false) == 2) ? 512 : 768);
   int split = target / tiles;       // 768 = 3 resident blocks per CU (the kernel is built for 3 waves/SIMD; x6: 2)
   if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
@@ -357,7 +360,9 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
       hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN, true>), dim3(tiles * split), dim3(256), lds, s, p);
     }
   } else {
-    const size_t lds = (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
+    const size_t lds = (sizeof(T) == 2 && BM == 128 && BN == 128)
+                           ? (size_t)BKP * (TrTile<BM * 2>::PITCH + TrTile<BN * 2>::PITCH)
+                           : (size_t)BKP * ((BM + BN) * sizeof(T) + 2 * WgLds<T>::PAD);
     hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN>), dim3(tiles * split), dim3(256), lds, s, p);
   }
   if (split > 1) {

@@ -46,6 +46,24 @@ def test_training_reduces_loss_and_is_deterministic(dtype):
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])      # bitwise reproducible (no float atomics)
 
 
+@pytest.mark.parametrize("model", ["resnet", "densenet"])
+def test_side_stream_wgrad_is_bitwise_the_single_stream_result(model, monkeypatch):
+    """Weight gradients forked to the side stream on EVERY layer (threshold 0; training only forks the large ones), with
+    the deferred join, against everything on one stream: same kernels, so the parameters must be bit-identical."""
+    from distributedpytorch_amd.nn import engine, layers
+    res = []
+    for dual in (True, False):
+        monkeypatch.setattr(engine, "DUAL_STREAM_BACKWARD", dual)
+        monkeypatch.setattr(layers, "SIDE_MIN_GFLOP", 0.0)
+        net, opt, dm = _make(torch.float32, model)
+        x, y = _batch(16, 64, net.in_channels, torch.float32)
+        for _ in range(4):
+            dm.train_step(x, y)
+        torch.cuda.synchronize()
+        res.append(net.store.p.clone())
+    assert torch.equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("model", ["resnet", "alexnet"])
 def test_hipgraph_replay_matches_eager(model):
     dtype = torch.bfloat16
