@@ -55,6 +55,77 @@ DPA_API int dpa_split3_planes(const float* w, void* out, long long n, hipStream_
   return dpa_launch_rc();
 }
 
+// ---- batched per-step weight preparation (nn/wprep.py) ------------------------------------------------------------------
+// Every conv layer needs, once per step, its filter as three bf16 planes (fprop), the transposed filter [C][RS][K]
+// (dgrad) and that one's planes: two or three tiny launches per layer (DenseNet-121: 359 launches and 1.2 ms of a 25 ms
+// step at batch 64).  This kernel does all of them in ONE launch from a device-side segment table.
+// One thread per 8 consecutive OUTPUT elements; a segment is found by binary search over the first chunk of each segment.
+struct WPrepSeg {
+  long long first_chunk;   // index of this segment's first 8-element chunk in the launch
+  long long n;             // elements (a multiple of 8)
+  const void* src;         // filter [K][RS][C] in the parameter arena (or its bf16 shadow)
+  void* dst;               // transposed: [C][RS][K] in the element type (or null); direct: unused
+  void* planes;            // three bf16 planes of the (transposed) filter, [3][n] (fp32 only, or null)
+  int K, RS, C, transposed;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) weight_prep_kernel(const WPrepSeg* __restrict__ segs, int nsegs, long long total_chunks) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total_chunks) return;
+  int lo = 0, hi = nsegs - 1;
+  while (lo < hi) {                          // last segment whose first_chunk <= g
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].first_chunk <= g) lo = mid; else hi = mid - 1;
+  }
+  const WPrepSeg sg = segs[lo];
+  const long long i0 = (g - sg.first_chunk) * 8;
+  const T* __restrict__ src = reinterpret_cast<const T*>(sg.src);
+  alignas(16) T v[8];
+  if (sg.transposed) {
+    // output order [c][rs][k]: k runs over 8 consecutive filters (K % 8 == 0), the source stride between them is RS * C
+    const int k = (int)(i0 % sg.K);
+    const long long t = i0 / sg.K;
+    const int rs = (int)(t % sg.RS), c = (int)(t / sg.RS);
+    const T* s0 = src + ((long long)k * sg.RS + rs) * sg.C + c;
+    const long long st = (long long)sg.RS * sg.C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = s0[e * st];
+    if (sg.dst) {
+      T* d = reinterpret_cast<T*>(sg.dst) + i0;
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(v);
+      }
+    }
+  } else {
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + i0);
+      *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + i0 + 4);
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (sg.planes) {
+      uint4 pl[3];
+      split3_frag(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])),
+                  make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])), pl);
+      bf16_t* out = reinterpret_cast<bf16_t*>(sg.planes);
+#pragma unroll
+      for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(out + (long long)part * sg.n + i0) = pl[part];
+    }
+  }
+}
+DPA_API int dpa_weight_prep(const void* segs, int nsegs, long long total_chunks, int dtype, hipStream_t s) {
+  if (nsegs <= 0 || total_chunks <= 0) return 0;
+  if (total_chunks > 0x7fffffffll * 256) return 1;
+  const dim3 grid((unsigned)((total_chunks + 255) / 256));
+  if (dtype == 1) hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, grid, dim3(256), 0, s, (const WPrepSeg*)segs, nsegs, total_chunks);
+  else            hipLaunchKernelGGL(weight_prep_kernel<float>, grid, dim3(256), 0, s, (const WPrepSeg*)segs, nsegs, total_chunks);
+  return dpa_launch_rc();
+}
+DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
+
 // NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
 // 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
 template <int TN, bool DGRAD, int NW, int MF, bool NOL = false, bool APL = false>

@@ -45,6 +45,7 @@ class Network:
     def forward(self, x: torch.Tensor, tape: Tape = None):
         """x: NHWC activation in the compute dtype with channels padded to `in_channels`."""
         ctx = Context(self.store, self.training, tape, rng=self.rng)
+        self.store.wprep.run(ctx)       # one launch for every filter transpose / plane split the layers registered
         out = self.net.forward(ctx, Act(x, False))
         return ctx, out
 

@@ -86,6 +86,8 @@ class ParamStore:
         self.p = self.g = self.p16 = self.b = self.nbt = None
         self.p_size = self.b_size = 0
         self.n_nbt = 0
+        from .wprep import WeightPrep
+        self.wprep = WeightPrep(self)       # batched per-step filter transposes / bf16 planes (nn/wprep.py)
 
     # ---------------------------------------------------------------- registration
     def add_conv_weight(self, name, cout, cin, kh, kw, init, trainable=True, flat_logical=False):
@@ -289,6 +291,7 @@ class Context:
         self.device = store.device
         self.dtype = store.compute_dtype
         self.cuda = store.device.type == "cuda"
+        self.wprep = None                    # set by WeightPrep.run when this pass prepared the filters in one launch
 
     @property
     def grad_enabled(self):

@@ -96,6 +96,17 @@ class Conv2d:
             setattr(self, which, buf)
         return ops.split3_planes(w, buf)
 
+    def _fwd_planes(self, ctx, w):
+        """The filter planes of this forward pass: from the batched per-step preparation (nn/wprep.py) when this pass ran
+        it, else through the per-layer kernel."""
+        if w.shape[3] % 32 or not ops.fp32_x6_active(ctx.cuda, w.dtype):
+            return None
+        r = self.store.wprep.get(ctx, (self.w.index, "f"), self.w, (w.shape[0], 1, w.numel() // w.shape[0]), False, True)
+        if r is not None:
+            self._w3 = None            # (the per-layer buffer of the registration step is no longer needed)
+            return r["pl"]
+        return self._planes(ctx, w, "_w3")
+
     def out_hw(self, h, w):
         return (ops.out_size(h, self.ksize[0], self.stride[0], self.padding[0]),
                 ops.out_size(w, self.ksize[1], self.stride[1], self.padding[1]))
@@ -110,10 +121,10 @@ class Conv2d:
         if self._as_gemm(x):      # whole-map 'valid' kernel = plain GEMM over the flattened (h, w, c) features
             w = w.view(w.shape[0], 1, 1, -1)
             ops.conv_fprop(x.view(n, 1, 1, -1), w, out, (1, 1), (0, 0), bias=bias, relu=relu,
-                           stats=stats, stats_shift=stats_shift, w3=self._planes(ctx, w, "_w3"))
+                           stats=stats, stats_shift=stats_shift, w3=self._fwd_planes(ctx, w))
         else:
             ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats, stats_shift=stats_shift,
-                           w3=self._planes(ctx, w, "_w3"))
+                           w3=self._fwd_planes(ctx, w))
         if stats is not None:
             self.last_stats_rows = ops.last_conv_stats_rows(ctx.cuda)
         return out
@@ -212,20 +223,26 @@ class Conv2d:
             and (x.grad_buf is None or x.grad_buf.is_contiguous())
         if gemm:
             w = w.view(w.shape[0], 1, 1, -1)
-        if self._wt is None or self._wt.shape[0] != w.shape[3]:
-            k, r, s, c = w.shape
-            self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
-        ops.transpose_krsc(w, self._wt)
-        wt3 = self._planes(ctx, self._wt, "_wt3")
+        k, r, s, c = w.shape
+        want_planes = k % 32 == 0 and ops.fp32_x6_active(ctx.cuda, w.dtype)
+        prep = self.store.wprep.get(ctx, (self.w.index, "t"), self.w, (k, r * s, c), True, want_planes)
+        if prep is not None:          # transposed filter (+ planes) made by this pass's batched preparation (nn/wprep.py)
+            wt, wt3 = prep["dst"].view(c, r, s, k), prep["pl"]
+            self._wt = self._wt3 = None
+        else:
+            if self._wt is None or self._wt.shape != (c, r, s, k):
+                self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
+            ops.transpose_krsc(w, self._wt)
+            wt, wt3 = self._wt, self._planes(ctx, self._wt, "_wt3")
         stride, padding = ((1, 1), (0, 0)) if gemm else (self.stride, self.padding)
         flat = (lambda t: t.view(t.shape[0], 1, 1, -1)) if gemm else (lambda t: t)
         fuse = self._bn_fusion(ctx, x, gemm) if last_use else None
         if x.grad is None:
             dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
-            rows = ops.conv_dgrad(dy, self._wt, flat(dx), stride, padding, wt3=wt3, bn_reduce=fuse)
+            rows = ops.conv_dgrad(dy, wt, flat(dx), stride, padding, wt3=wt3, bn_reduce=fuse)
             x.grad = dx
         else:
-            rows = ops.conv_dgrad(dy, self._wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3, bn_reduce=fuse)
+            rows = ops.conv_dgrad(dy, wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3, bn_reduce=fuse)
         if fuse is not None:
             x.bn_slab = fuse[6][:rows]
 

@@ -62,6 +62,10 @@ def split3_planes(w, out):
     return _hip().split3_planes(w, out)
 
 
+def weight_prep(table, nsegs, total_chunks, dtype):
+    return _hip().weight_prep(table, nsegs, total_chunks, dtype)
+
+
 def fp32_x6_active(cuda, dtype):
     """Is the pre-split-filter fast path of the fp32 convolutions worth preparing (GPU, fp32, x6 arithmetic)?"""
     if not cuda or dtype != torch.float32:

@@ -43,6 +43,15 @@ def split3_planes(w, out):
     return out
 
 
+def weight_prep(table, nsegs, total_chunks, dtype):
+    """One launch for every registered per-step filter transformation (nn/wprep.py; csrc/hip/conv_x6p.hip:
+    weight_prep_kernel).  table: int64 device tensor [nsegs, 7] in the layout of struct WPrepSeg."""
+    lib = native.hip_lib()
+    assert table.dtype == torch.int64 and table.is_contiguous() and lib.dpa_weight_prep_seg_size() == 56
+    lib.dpa_weight_prep(VP(table.data_ptr()), ctypes.c_int(nsegs), ctypes.c_longlong(total_chunks), ctypes.c_int(_DT[dtype]),
+                        native.stream_ptr())
+
+
 def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None, _nol=None, _x3=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats: fp32 [rows, 2, Cout] slab written with per-block
     (sum, sumsq) of the stored outputs minus the per-channel `stats_shift` (0 if None); rows = stats_rows(M, Cout)."""

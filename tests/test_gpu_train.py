@@ -64,6 +64,31 @@ def test_side_stream_wgrad_is_bitwise_the_single_stream_result(model, monkeypatc
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("model,dtype", [("resnet", torch.float32), ("alexnet", torch.float32), ("densenet", torch.float32),
+                                         ("resnet", torch.bfloat16)])
+def test_batched_weight_prep_is_bitwise_the_per_layer_path(model, dtype, monkeypatch):
+    """nn/wprep.py: all filter transposes / bf16 plane splits of a step in ONE launch (from the second step on) against
+    the per-layer kernels: same values, so training must be bit-identical - including Linear-as-GEMM layers (AlexNet)
+    and an evaluation pass between training steps."""
+    from distributedpytorch_amd.nn import wprep
+    res = []
+    for enabled in (True, False):
+        monkeypatch.setattr(wprep, "ENABLED", enabled)
+        net, opt, dm = _make(dtype, model)
+        x, y = _batch(8, 64, net.in_channels, dtype)
+        for it in range(4):
+            dm.train_step(x, y)
+            if it == 1:
+                net.eval()
+                _, out = net.forward(x)
+                ev = out.data.clone() if hasattr(out, "data") else out[0].data.clone()
+                net.train()
+        torch.cuda.synchronize()
+        assert (len(net.store.wprep.ready) > 0) == enabled
+        res.append((net.store.p.clone(), ev))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("model", ["resnet", "alexnet"])
 def test_hipgraph_replay_matches_eager(model):
     dtype = torch.bfloat16
