@@ -68,8 +68,34 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   out[(size_t)blockIdx.x * width + c] = s;
 }
 
-// one thread per channel over a (small) slab [rows][2][C]
-__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ slab, int rows, int C, float count,
+// Column sums of a slab [rows][2][C] for the finalize kernels: a block is 64 channels x FIN_RL row lanes (lane l sums rows
+// l, l + FIN_RL, ... - independent loads, 1/16 of the serial depth of one thread per channel), then lane 0 combines the
+// lanes in a fixed order.  Returns true in the threads that own a channel (and hold its sums).  With it a slab of up to
+// FIN_MAX_ROWS rows is finalized directly: no slab_reduce launch in front (batch 64: most BatchNorm layers of the zoo).
+constexpr int FIN_RL = 16, FIN_T = 64 * FIN_RL, FIN_MAX_ROWS = 512;
+__device__ __forceinline__ bool slab_sum2(const float* __restrict__ slab, int rows, int C, bool want_q, float& s, float& q) {
+  __shared__ float red[2][FIN_RL][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = rl; r < rows; r += FIN_RL) {
+      a += slab[((size_t)r * 2) * C + c];
+      if (want_q) b += slab[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][rl][cl] = a; red[1][rl][cl] = b;
+  __syncthreads();
+  if (rl != 0 || c >= C) return false;
+  s = 0.f; q = 0.f;
+#pragma unroll
+  for (int l = 0; l < FIN_RL; ++l) { s += red[0][l][cl]; q += red[1][l][cl]; }
+  return true;
+}
+
+// slab [rows][2][C] -> batch statistics and the folded (scale, shift) of the normalisation
+__global__ void __launch_bounds__(FIN_T) bn_finalize_kernel(const float* __restrict__ slab, int rows, int C, float count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                                          long long* __restrict__ nbt, float momentum, float eps,
@@ -80,11 +106,10 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict
   // step's batch mean, kept in `stat_shift` and refreshed here), so var = E[(x-c)^2] - (E[x-c])^2 subtracts two SMALL
   // numbers even when |mean| >> std (post-ReLU inputs of DenseNet's pre-activation BN, the inception stem) - the
   // plain E[x^2] - mean^2 in fp32 loses every digit of the variance there (mean 100, std 0.1: 10000.01 - 10000).
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  float s = 0.f, q = 0.f;
-  for (int r = 0; r < rows; ++r) { s += slab[((size_t)r * 2) * C + c]; q += slab[((size_t)r * 2 + 1) * C + c]; }
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  float s, q;
+  if (!slab_sum2(slab, rows, C, true, s, q)) return;
   const float c0 = stat_shift ? stat_shift[c] : 0.f;
   const float dm = s / count;
   const float mean = c0 + dm;
@@ -250,16 +275,15 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(T* __restrict__ dy, 
 // slab [rows][2][C] -> dbeta = sum dz, dgamma = sum dz*xhat (written or accumulated into the fp32 grad arena) and the
 // folded per-channel coefficients of dx = A*dz + B*x + D  (coef[0..3C) = A | B | D):
 //   A = gamma*invstd   B = -gamma*invstd^2*dgamma/M   D = -A*dbeta/M - B*mean
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ slab, int rows, int C,
+__global__ void __launch_bounds__(FIN_T) bn_bwd_finalize_kernel(const float* __restrict__ slab, int rows, int C,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ sums, int accumulate,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, float invM,
                                                              float* __restrict__ coef) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f, q = 0.f;
-  for (int r = 0; r < rows; ++r) { s += slab[((size_t)r * 2) * C + c]; q += slab[((size_t)r * 2 + 1) * C + c]; }
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  float s, q;
+  if (!slab_sum2(slab, rows, C, true, s, q)) return;
   sums[c] = s; sums[C + c] = q;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + q : q;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s : s;
@@ -360,7 +384,7 @@ static int rows_per_block(long long M, int* nblocks) {
 
 // Reduce a [rows][2][C] slab down to <= ROWS_L2 rows if it is tall. Returns the slab to finalize from.
 static const float* shrink_slab(const float* slab, int* rows, int C, float* scratch, hipStream_t s) {
-  if (*rows <= 64) return slab;
+  if (*rows <= FIN_MAX_ROWS) return slab;
   // tall slabs (large batches: 25 088 rows at batch 1024) get 128 row groups so that the reduction covers the chip;
   // small ones stay at 32 (the finalize kernel walks the groups serially)
   const int groups = *rows >= 2048 ? ROWS_L2 : 32;
@@ -390,7 +414,7 @@ DPA_API int dpa_bn_finalize(const float* slab, int rows, int C, long long count,
                              float* mean_out, float* invstd_out, float* scale_out, float* shift_out, float* scratch,
                              float* stat_shift, hipStream_t s) {
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, (float)count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(FIN_T), 0, s, sl, rows, C, (float)count, gamma, beta,
                      running_mean, running_var, nbt, momentum, eps, mean_out, invstd_out, scale_out, shift_out, stat_shift);
   return dpa_launch_rc();
 }
@@ -420,7 +444,7 @@ DPA_API int dpa_bn_bwd_reduce(void* dy, int dy_cs, const void* y, int y_cs, cons
                                      y_cs, (const float*)x, x_cs, mean, invstd, M, C, slab, rpb, mscale, mshift);
   int rows = nb;
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(FIN_T), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
                      mean, invstd, gamma, 1.0f / (float)M, coef);
   return dpa_launch_rc();
 }
@@ -430,7 +454,7 @@ DPA_API int dpa_bn_bwd_from_slab(const float* slab, int rows, const float* mean,
                                   long long M, int C, float* scratch, float* dgamma, float* dbeta, float* sums, float* coef,
                                   int accumulate, hipStream_t s) {
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(FIN_T), 0, s, sl, rows, C, dgamma, dbeta, sums, accumulate,
                      mean, invstd, gamma, 1.0f / (float)M, coef);
   return dpa_launch_rc();
 }
@@ -445,12 +469,11 @@ DPA_API int dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, co
 }
 
 // Per-channel column sum of a tall activation (conv bias gradients): stats slab -> fixed-order reduce.
-__global__ void __launch_bounds__(64) slab_colsum_finalize_kernel(const float* __restrict__ slab, int rows, int C,
+__global__ void __launch_bounds__(FIN_T) slab_colsum_finalize_kernel(const float* __restrict__ slab, int rows, int C,
                                                                   float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += slab[((size_t)r * 2) * C + c];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  float s, q;
+  if (!slab_sum2(slab, rows, C, false, s, q)) return;
   out[c] = accumulate ? out[c] + s : s;
 }
 DPA_API int dpa_colsum_tall(const void* x, int dtype, long long M, int C, int cs, float* slab, float* scratch, float* out,
@@ -459,6 +482,6 @@ DPA_API int dpa_colsum_tall(const void* x, int dtype, long long M, int C, int cs
   if (rc0) return rc0;
   int rows = dpa_bn_slab_rows(M);
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
-  hipLaunchKernelGGL(slab_colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sl, rows, C, out, accumulate);
+  hipLaunchKernelGGL(slab_colsum_finalize_kernel, dim3((C + 63) / 64), dim3(FIN_T), 0, s, sl, rows, C, out, accumulate);
   return dpa_launch_rc();
 }
