@@ -292,7 +292,9 @@ __global__ void __launch_bounds__(FIN_T) bn_bwd_finalize_kernel(const float* __r
   coef[c] = A; coef[C + c] = B; coef[2 * C + c] = -A * s * invM - B * mean[c];
 }
 
-template <typename T>
+// ACC: dx += (instead of =): the gradient of a concat prefix that later layers already contributed to (DenseNet) - saves
+// the temporary and the separate add kernel.
+template <typename T, bool ACC = false>
 __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz, int dz_cs, const T* x, int x_cs,
                                                         const float* __restrict__ coef, T* dx, int dx_cs,
                                                         long long M, int C, int rowsPerBlock,
@@ -324,11 +326,12 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
     constexpr int UNR = 4;                      // rows per trip, loads first (see bn_apply_kernel)
     long long m = r0 + rl;
     for (; m + (long long)(UNR - 1) * rowLanes < r1; m += (long long)UNR * rowLanes) {
-      Vec16<T> g[UNR], xv[UNR];                 // dx may alias x: each thread reads its chunks before writing them
+      Vec16<T> g[UNR], xv[UNR], av[UNR];        // dx may alias x: each thread reads its chunks before writing them
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         g[u].load(dz + (m + (long long)u * rowLanes) * dz_cs + c);
         xv[u].load(x + (m + (long long)u * rowLanes) * x_cs + c);
+        if (ACC) av[u].load(dx + (m + (long long)u * rowLanes) * dx_cs + c);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
         for (int e = 0; e < VEC; ++e) {
           const float xe = xv[u].get(e);
           const float ge = (xe * msc[e] + msh[e] > 0.f) ? g[u].get(e) : 0.f;   // (no mask: 0*x + 1 > 0 always)
-          o.set(e, A[e] * ge + B[e] * xe + D[e]);
+          o.set(e, A[e] * ge + B[e] * xe + D[e] + (ACC ? av[u].get(e) : 0.f));
         }
         o.store(dx + (m + (long long)u * rowLanes) * dx_cs + c);
       }
@@ -345,12 +348,13 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
     for (; m < r1; m += rowLanes) {
       Vec16<T> g; g.load(dz + m * dz_cs + c);
       Vec16<T> xv; xv.load(x + m * x_cs + c);
+      Vec16<T> av; if (ACC) av.load(dx + m * dx_cs + c);
       Vec16<T> o;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float xe = xv.get(e);
         const float ge = (xe * msc[e] + msh[e] > 0.f) ? g.get(e) : 0.f;
-        o.set(e, A[e] * ge + B[e] * xe + D[e]);
+        o.set(e, A[e] * ge + B[e] * xe + D[e] + (ACC ? av.get(e) : 0.f));
       }
       o.store(dx + m * dx_cs + c);
     }
@@ -459,12 +463,13 @@ DPA_API int dpa_bn_bwd_from_slab(const float* slab, int rows, const float* mean,
   return dpa_launch_rc();
 }
 DPA_API int dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, const float* coef, void* dx, int dx_cs,
-                           long long M, int C, int dtype, hipStream_t s, const float* mscale, const float* mshift) {
+                           long long M, int C, int dtype, hipStream_t s, const float* mscale, const float* mshift, int accumulate) {
   int nb; const int rpb = ew_rows_per_block(M, C, dtype == 1 ? 2 : 4, &nb);
-  if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, dz_cs,
-                                     (const bf16_t*)x, x_cs, coef, (bf16_t*)dx, dx_cs, M, C, rpb, mscale, mshift);
-  else            hipLaunchKernelGGL(bn_bwd_dx_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, dz_cs,
-                                     (const float*)x, x_cs, coef, (float*)dx, dx_cs, M, C, rpb, mscale, mshift);
+#define DPA_BWD_DX(T, ACC) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, ACC>), dim3(nb), dim3(256), 0, s, (const T*)dz, dz_cs, \
+                                               (const T*)x, x_cs, coef, (T*)dx, dx_cs, M, C, rpb, mscale, mshift)
+  if (dtype == 1) { if (accumulate) DPA_BWD_DX(bf16_t, true); else DPA_BWD_DX(bf16_t, false); }
+  else            { if (accumulate) DPA_BWD_DX(float, true);  else DPA_BWD_DX(float, false); }
+#undef DPA_BWD_DX
   return dpa_launch_rc();
 }
 

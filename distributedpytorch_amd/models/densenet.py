@@ -50,12 +50,16 @@ class DenseBlock:
         for layer in self.layers:
             xl = Act(buf[..., :c], rec)
             if rec:
-                def add_into_g(xl=xl, c=c):
-                    g, xl.grad = xl.grad, None
-                    G = st["G"]
-                    ops.add(G[..., :c], g, G[..., :c])
-                ctx.tape.push(add_into_g)                                              # after this layer's norm1 backward
+                def release(xl=xl):
+                    xl.grad = None
+                ctx.tape.push(release)                                                 # after this layer's norm1 backward
             h = layer.norm1(ctx, xl, relu=True)
+            if rec:
+                def preset(xl=xl, c=c):
+                    # norm1's backward ADDS its input gradient straight into the block gradient's channel prefix
+                    # (bn_bwd_dx accumulate mode): no temporary and no separate add kernel per layer
+                    xl.grad = st["G"][..., :c]
+                ctx.tape.push(preset)                                                  # before this layer's norm1 backward
             h = layer.conv1_norm2(ctx, h, relu=True, last_use=True)      # sole reader of norm1's output
             yl = layer.conv2(ctx, h, out=buf[..., c: c + self.growth], last_use=True)
             if rec:

@@ -294,7 +294,7 @@ class BatchNorm2d:
                                a[2], a[3])
         return a
 
-    def backward(self, ctx: Context, dy, y_for_mask, z, dx_out, mask_from_x=False):
+    def backward(self, ctx: Context, dy, y_for_mask, z, dx_out, mask_from_x=False, accumulate=False):
         """dz = dy*(y>0) in place; dgamma/dbeta -> arena; returns dx (written into dx_out).  mask_from_x (BN+ReLU with no
         residual, nobody else needs the masked dy): the mask is recomputed from z with the forward's folded
         coefficients a[2], a[3] - y is not read and dy is not rewritten."""
@@ -308,11 +308,11 @@ class BatchNorm2d:
         if self.trainable:
             ctx.tape.ready(self.gamma)
             ctx.tape.ready(self.beta)
-        ops.bn_bwd_dx(dy, z, a[6:9], dx_out, mask_scale=ms, mask_shift=mh)
+        ops.bn_bwd_dx(dy, z, a[6:9], dx_out, mask_scale=ms, mask_shift=mh, accumulate=accumulate)
         return dx_out
 
 
-def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m):
+def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m, accumulate=False):
     """BatchNorm2d.backward when a dgrad epilogue already masked dy and reduced it (Act.bn_slab)."""
     st = bn.store
     a = bn.aux(ctx.device)
@@ -322,7 +322,7 @@ def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m):
     if bn.trainable:
         ctx.tape.ready(bn.gamma)
         ctx.tape.ready(bn.beta)
-    ops.bn_bwd_dx(dy, z, a[6:9], dx_out)
+    ops.bn_bwd_dx(dy, z, a[6:9], dx_out, accumulate=accumulate)
     return dx_out
 
 
@@ -446,13 +446,22 @@ class BNAct:
                 dy = y.grad
                 y.grad = None
                 slab, y.bn_slab, y.bn_src = y.bn_slab, None, None
-                dx = ctx.empty((n, h, w, c))
-                if slab is not None:
-                    _bn_backward_from_slab(bn, ctx, dy, x.data, dx, slab, m)
+                # dx goes straight into x's gradient: added to what later consumers already left there (a DenseNet concat
+                # prefix), or written into its preassigned slot - no temporary, no separate add / copy kernel
+                acc = False
+                if x.needs_grad and x.grad is not None:
+                    dx, acc = x.grad, True
+                elif x.needs_grad and x.grad_buf is not None:
+                    dx = x.grad_buf
                 else:
-                    bn.backward(ctx, dy, y.data if relu else None, x.data, dx, mask_from_x=relu and ctx.training)
-                if x.needs_grad:
-                    accumulate_grad(x, dx)
+                    dx = ctx.empty((n, h, w, c))
+                if slab is not None:
+                    _bn_backward_from_slab(bn, ctx, dy, x.data, dx, slab, m, accumulate=acc)
+                else:
+                    bn.backward(ctx, dy, y.data if relu else None, x.data, dx, mask_from_x=relu and ctx.training,
+                                accumulate=acc)
+                if x.needs_grad and x.grad is None:
+                    x.grad = dx
             ctx.tape.push(bw)
         return y
 

@@ -117,10 +117,10 @@ def bn_bwd_from_slab(slab, m, mean, invstd, gamma, dgamma, dbeta, sums, coef, sc
                                 ptr(dbeta), ptr(sums), ptr(coef), int(accumulate), stream_ptr())
 
 
-def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None):
+def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None, accumulate=False):
     m, c, zcs = _mc(dz)
     _lib().dpa_bn_bwd_dx(ptr(dz), zcs, ptr(x), _mc(x)[2], ptr(coef), ptr(dx), _mc(dx)[2], I64(m), c, _DT[dz.dtype],
-                         stream_ptr(), ptr(mask_scale), ptr(mask_shift))
+                         stream_ptr(), ptr(mask_scale), ptr(mask_shift), int(bool(accumulate)))
     return dx
 
 

@@ -203,11 +203,13 @@ def bn_bwd_from_slab(slab, m, mean, invstd, gamma, dgamma, dbeta, sums, coef, sc
     coef[2].copy_(-a * s / m - b * mean)
 
 
-def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None):
+def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None, accumulate=False):
     g = dz.float()
     if mask_scale is not None:
         g = g * ((x.float() * mask_scale + mask_shift) > 0)
     out = coef[0] * g + coef[1] * x.float() + coef[2]
+    if accumulate:
+        out = out + dx.float()
     dx.copy_(out.to(dx.dtype))
     return dx
 
