@@ -128,9 +128,17 @@ DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
 
 // NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
 // 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
-template <int TN, bool DGRAD, int NW, int MF, bool NOL = false, bool APL = false>
-__global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p) {
-  constexpr int BM = 32 * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
+// TMW row tiles (16 rows each) per wave: 2 -> 128-row block tile, two blocks per CU.  4 -> 256-row block tile, ONE block per
+// CU (112 KB of LDS, one wave per SIMD with up to 512 registers): every filter fragment a wave reads from LDS feeds four
+// row tiles instead of two, so LDS reads per MFMA drop by 43 % and LDS-DMA bytes per MFMA by 30 %.  EXPERIMENT, not the
+// default: it is 10-15 % slower on every ResNet-50 layer (3x3 steady state 208 -> 178 TFLOP/s) - LDS bytes are not what
+// holds the 128-row tile at 64 % MFMA utilisation; with one wave per SIMD nothing covers a wave's own LDS / barrier waits
+// and operand splits, which the second resident block of the 128-row configuration does.
+template <int TN, bool DGRAD, int NW, int MF, bool NOL = false, bool APL = false, int TMW = 2>
+__global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(const ConvParams p) {
+  static_assert(TMW == 2 || (TMW == 4 && !NOL && !APL), "experiment instantiations exist for the 128-row tile only");
+  constexpr int WROWS = 16 * TMW;                  // rows of the block tile a wave owns
+  constexpr int BM = WROWS * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
   constexpr int AP_BYTES = BM * 64;                // one plane of the activation tile (APL: experiment, see ConvParams::src3)
   constexpr int A_BYTES = APL ? 3 * AP_BYTES : BM * 128, BP_BYTES = BN * 64;
   constexpr int STAGE_BYTES = A_BYTES + 3 * BP_BYTES;
@@ -275,7 +283,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
 
   BnReduceLane<float, 4> bnr;                  // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
   if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + (lane % LPR) * 4); }
-  // 16 staged rows (block rows m0 + wave*32 + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map, fused BN reduce.
+  // 16 staged rows (block rows m0 + wave*WROWS + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map, fused BN reduce.
   // Two phases so that every global read of the 16 rows (addend, and for the fused BatchNorm reduction x and y) is in
   // flight before the first one is consumed: issued one row group at a time, their latency was exposed 16 / RPI times
   // per wave and the fused reduction cost more than the kernel it replaced.
@@ -286,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
     for (int rr = 0; rr < 16; rr += RPI) {
       const int r = rr + lane / LPR;
       const int cc = (lane % LPR) * 4;
-      const int m = m0 + wave * 32 + i * 16 + r;
+      const int m = m0 + wave * WROWS + i * 16 + r;
       const int col = n0 + cc;
       float4 v = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc]);
       if (m < p.M && col < p.dC) {
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
     const float* __restrict__ by = reinterpret_cast<const float*>(p.bnr_y);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int m = m0 + wave * 32 + i * 16 + g * RPI + lane / LPR;
+      const int m = m0 + wave * WROWS + i * 16 + g * RPI + lane / LPR;
       ok[g] = m < p.M && col < p.dC;
       size_t pixel = ok[g] ? (size_t)m : 0;
       if (DGRAD && (p.sh != 1 || p.sw != 1) && ok[g]) {      // class row -> (img, hi, wi) of the full gradient tensor
@@ -374,7 +382,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
   const bool interior = m0 + BM <= p.M;          // block-uniform
 
   {
-    constexpr int TM = 2;
+    constexpr int TM = TMW;
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -385,6 +393,39 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
     constexpr int JH = TN > 4 ? 4 : TN;                                // filter fragments held in registers at a time
 
     if (nkt > 0) issue_tile(0, 0);
+    if constexpr (TMW == 4) {
+      // One wave per SIMD: ALL fragments of the K-tile go to registers first (8 activation + 3 TN filter reads), then the
+      // next tile's DMA is issued (the compiler puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA
+      // issue, so no read may come after it), and the 24 TN MFMAs of the tile cover its latency.
+      for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* tA = smem + (kt & 1) * STAGE_BYTES;
+        const char* tB = tA + A_BYTES;
+        uint4 fa[2][TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
+        uint4 bp[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
+        if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+        uint4 ap[TM][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+      }
+    } else
     for (int kt = 0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -397,13 +438,13 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int part = 0; part < 3; ++part)
-            ap[i][part] = *reinterpret_cast<const uint4*>(tA + part * AP_BYTES + (wave * 32 + i * 16) * 64 + b_frag);
+            ap[i][part] = *reinterpret_cast<const uint4*>(tA + part * AP_BYTES + (wave * WROWS + i * 16) * 64 + b_frag);
       } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * 32 + i * 16 + fr, 2 * fq + ks));
+          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
       }
       uint4 bp[JH][3];
 #pragma unroll
@@ -454,7 +495,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
     }
     __syncthreads();
 
-    // ---- epilogue: acc[i][j][e] = D[row = wave*32 + i*16 + fq*4 + e][col = j*16 + fr] ---------------------------------
+    // ---- epilogue: acc[i][j][e] = D[row = wave*WROWS + i*16 + fq*4 + e][col = j*16 + fr] ---------------------------------
     float csum[TN], csq[TN], bj[TN], cj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -479,7 +520,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][j][e] + bj[j] - cj[j];
-            if (!interior && m0 + wave * 32 + i * 16 + fq * 4 + e >= p.M) v = 0.f;
+            if (!interior && m0 + wave * WROWS + i * 16 + fq * 4 + e >= p.M) v = 0.f;
             csum[j] += v; csq[j] += v * v;
           }
       }
@@ -517,9 +558,9 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
   }
 }
 
-template <int TN, int NW, int MF>
+template <int TN, int NW, int MF, int TMW = 2>
 static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
-  constexpr int BN = TN * 16, BM = 32 * NW;
+  constexpr int BN = TN * 16, BM = 16 * TMW * NW;
   p.tilesM = (p.M - p.m_off + BM - 1) / BM;
   p.tilesN = (p.dC + BN - 1) / BN;
   static const int pad = [] { const char* e = getenv("DPA_X6P_LDS_PAD"); return e ? atoi(e) : 0; }();      // residency experiments
@@ -527,6 +568,11 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
+  if constexpr (TMW == 4) {
+    if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, false, false, 4>), grid, block, lds, s, p);
+    else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, false, false, 4>), grid, block, lds, s, p);
+    return;
+  } else {
   if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF>), grid, block, lds, s, p);
   else if (p.src3) {
     const size_t lds3 = (size_t)2 * (3 * BM * 64 + 3 * BN * 64);
@@ -534,6 +580,7 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   }
   else if (p.nol_scale) hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, true>), grid, block, lds, s, p);
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
+  }
 }
 
 // Fewest tiles for which the pre-split kernel is taken (DPA_X6P_MIN_TILES, default 96: profiles/r2_x6p_small_batch_sweep.txt).  v >= 0 sets it and returns the
@@ -551,9 +598,18 @@ DPA_API int dpa_x6p_min_tiles(int v) {
 static long long x6p_tiles(const ConvParams& p, bool narrow) {
   return (long long)((p.M + 127) / 128) * ((p.dC + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
 }
+// which: 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_TALL_MIN (default 512).  v >= 0 sets the knob and returns
+// the previous value (the kernel tests steer small shapes to each variant with it); v < 0 only reads it.
+DPA_API int dpa_x6p_knob(int which, int v) {
+  static int cur[3] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
+                          [] { const char* e = getenv("DPA_X6P_TALL_MIN"); return e ? atoi(e) : 512; }()};
+  if (which < 1 || which > 2) return -1;
+  const int prev = cur[which];
+  if (v >= 0) cur[which] = v;
+  return prev;
+}
 static bool x6p_narrow(const ConvParams& p) {
-  static const int below = [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }();
-  return p.dC <= 64 || x6p_tiles(p, false) < below;
+  return p.dC <= 64 || x6p_tiles(p, false) < dpa_x6p_knob(1, -1);
 }
 // Can this (sub-)problem take the pre-split kernel?  (called by conv_igemm.hip's launch_tiles for fp32 in x6 mode)
 bool dpa_x6p_eligible(const ConvParams& p) {
@@ -570,7 +626,13 @@ bool dpa_x6p_eligible(const ConvParams& p) {
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   p.m_off = 0; p.stats_row0 = 0;
   static const int apl_tn = [] { const char* e = getenv("DPA_X6PP_TN"); return e ? atoi(e) : 8; }();      // experiment: tile width with src3
+  // 256-row tile (one block per CU): opt-in experiment (DPA_X6P_TALL=1, for problems with at least DPA_X6P_TALL_MIN such
+  // tiles) - measured 10-15 % SLOWER than the 128-row tile on every ResNet-50 layer (profiles/r2_x6p_tall_tile.txt)
+  static const int tall = [] { const char* e = getenv("DPA_X6P_TALL"); return e ? atoi(e) : 0; }();
+  const int tall_min = dpa_x6p_knob(2, -1);
+  const long long tall_tiles = (long long)((p.M + 255) / 256) * ((p.dC + 127) / 128);
   if (x6p_narrow(p) || (p.src3 && apl_tn == 4)) x6p_launch<4, 4, 16>(p, dgrad, s);
+  else if (tall && !p.src3 && !p.nol_scale && tall_tiles >= tall_min) x6p_launch<8, 4, 16, 4>(p, dgrad, s);
   else                                       x6p_launch<8, 4, 16>(p, dgrad, s);
   return p.tilesM;
 }

@@ -40,6 +40,8 @@ def test_conv_fprop_dgrad_wgrad(shape, dtype, fp32_mode):
     from distributedpytorch_amd.ops import hip_conv
     if dtype == torch.bfloat16 and fp32_mode == "exact":
         pytest.skip("the fp32 arithmetic mode does not affect the bf16 kernels")
+    if x6p_variant != "narrow" and not (dtype == torch.float32 and fp32_mode == "x6"):
+        pytest.skip("the tile variants exist in the pre-split fp32 kernel only")
     N, H, W, C, K, k, s, pd = shape
     g = torch.Generator(device="cuda").manual_seed(1234)
     x = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
@@ -135,8 +137,21 @@ PRESPLIT_SHAPES = [
 ]
 
 
+@pytest.fixture(params=["narrow", "wide", "tall"])
+def x6p_variant(request):
+    """Steer the (small) test problems to each tile variant of the pre-split kernel: 128 x 64, 128 x 128 (two blocks per CU)
+    and 256 x 128 (one block per CU); production picks by problem size (DPA_X6P_NARROW_BELOW / DPA_X6P_TALL_MIN)."""
+    from distributedpytorch_amd.ops import native
+    lib = native.hip_lib()
+    big = 1 << 30
+    narrow_below, tall_min = {"narrow": (big, big), "wide": (0, big), "tall": (0, 1)}[request.param]
+    prev = lib.dpa_x6p_knob(1, narrow_below), lib.dpa_x6p_knob(2, tall_min)
+    yield request.param
+    lib.dpa_x6p_knob(1, prev[0]); lib.dpa_x6p_knob(2, prev[1])
+
+
 @pytest.mark.parametrize("shape", PRESPLIT_SHAPES)
-def test_conv_presplit_x6_kernel(shape):
+def test_conv_presplit_x6_kernel(shape, x6p_variant):
     """csrc/hip/conv_x6p.hip (fp32 through the bf16 matrix pipe with the filter pre-split into three bf16 planes, waves
     stacked along M) against the fp32 PyTorch reference: fprop with the whole fused epilogue (bias, shifted BN statistics,
     addend, ReLU, channel-sliced destination) and dgrad (fresh and accumulating in place)."""
@@ -158,7 +173,8 @@ def test_conv_presplit_x6_kernel(shape):
         shift = torch.randn(K, device="cuda", generator=g) * 0.1
         hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd), bias=b, stats=stats, stats_shift=shift, w3=w3)
         rows = hip_conv.last_stats_rows[0]
-        assert rows == (M + 127) // 128                 # one slab row per 128-row tile: the pre-split kernel ran
+        tile_rows = 256 if (x6p_variant == "tall" and K > 64) else 128
+        assert rows == (M + tile_rows - 1) // tile_rows     # one slab row per M-tile of that variant: the pre-split kernel ran
         yr = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=s, padding=pd).permute(0, 2, 3, 1)
         rtol, atol = _tol(torch.float32, k * k * C)
         torch.testing.assert_close(y, yr, rtol=rtol, atol=atol * 10)
@@ -204,7 +220,7 @@ BNR_SHAPES = [
 @pytest.mark.parametrize("mask", ["y", "x", "none"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", BNR_SHAPES)
-def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode):
+def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_variant):
     """conv_dgrad(bn_reduce=...): the epilogue masks the gradient it stores and writes the partial sums of the
     BatchNorm-backward reduction; compared with the unfused dgrad followed by the plain formulas in fp64."""
     from distributedpytorch_amd.ops import hip_conv
