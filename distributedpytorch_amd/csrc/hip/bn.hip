@@ -14,10 +14,13 @@
 
 #define ROWS_L2 128  // rows of the second-level slab (= blocks along the row axis of slab_reduce: 32 left most CUs idle)
 
-template <typename T>
-__global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, long long M, int C, int cs,
+// MASK (bias gradient of conv + bias + ReLU): x is a gradient that is first masked IN PLACE with y > 0 - the ReLU backward
+// and the column sum in one pass over the tensor instead of two kernels.
+template <typename T, bool MASK = false>
+__global__ void __launch_bounds__(256) bn_stats_kernel(T* __restrict__ x, long long M, int C, int cs,
                                                        float* __restrict__ slab, int rowsPerBlock,
-                                                       const float* __restrict__ shift) {
+                                                       const float* __restrict__ shift,
+                                                       const T* __restrict__ y = nullptr, int y_cs = 0) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[2][256][VEC > 4 ? 9 : 5];
   const int cpr = C / VEC;
@@ -39,6 +42,12 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
       }
       for (long long r = r0 + rl; r < r1; r += rowLanes) {
         Vec16<T> v; v.load(x + r * cs + (long long)cc * VEC);
+        if constexpr (MASK) {
+          Vec16<T> yv; yv.load(y + r * y_cs + (long long)cc * VEC);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) if (!(yv.get(e) > 0.f)) v.set(e, 0.f);
+          v.store(x + r * cs + (long long)cc * VEC);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { const float f = v.get(e) - c0[e]; s[e] += f; q[e] += f * f; }
       }
@@ -402,15 +411,15 @@ DPA_API int dpa_bn_slab_rows(long long M) { int nb; rows_per_block(M, &nb); retu
 // scratch: >= ROWS_L2*2*C floats.  slab: [rows][2][C]
 DPA_API int dpa_bn_stats(const void* x, int dtype, long long M, int C, int cs, float* slab, const float* shift, hipStream_t s) {
   int nb; const int rpb = rows_per_block(M, &nb);
-  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rpb, shift);
-  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rpb, shift);
+  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (bf16_t*)x, M, C, cs, slab, rpb, shift, (const bf16_t*)nullptr, 0);
+  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nb), dim3(256), 0, s, (float*)x, M, C, cs, slab, rpb, shift, (const float*)nullptr, 0);
   return dpa_launch_rc();
 }
 // Same slab, caller-chosen row blocking (the split-K conv path rebuilds the stats its fused epilogue would have written).
 DPA_API int dpa_bn_stats_rows(const void* x, int dtype, long long M, int C, int cs, float* slab, int rowsPerBlock,
                                int nblocks, const float* shift, hipStream_t s) {
-  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)x, M, C, cs, slab, rowsPerBlock, shift);
-  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblocks), dim3(256), 0, s, (const float*)x, M, C, cs, slab, rowsPerBlock, shift);
+  if (dtype == 1) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, s, (bf16_t*)x, M, C, cs, slab, rowsPerBlock, shift, (const bf16_t*)nullptr, 0);
+  else            hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblocks), dim3(256), 0, s, (float*)x, M, C, cs, slab, rowsPerBlock, shift, (const float*)nullptr, 0);
   return dpa_launch_rc();
 }
 DPA_API int dpa_bn_finalize(const float* slab, int rows, int C, long long count, const float* gamma, const float* beta,
@@ -486,6 +495,20 @@ DPA_API int dpa_colsum_tall(const void* x, int dtype, long long M, int C, int cs
   const int rc0 = dpa_bn_stats(x, dtype, M, C, cs, slab, nullptr, s);
   if (rc0) return rc0;
   int rows = dpa_bn_slab_rows(M);
+  const float* sl = shrink_slab(slab, &rows, C, scratch, s);
+  hipLaunchKernelGGL(slab_colsum_finalize_kernel, dim3((C + 63) / 64), dim3(FIN_T), 0, s, sl, rows, C, out, accumulate);
+  return dpa_launch_rc();
+}
+
+// Bias gradient of conv + bias + ReLU: dy *= (y > 0) in place and out (+)= column sums of the masked dy, one pass.
+DPA_API int dpa_relu_bwd_colsum(void* dy, int dy_cs, const void* y, int y_cs, int dtype, long long M, int C, float* slab,
+                                 float* scratch, float* out, int accumulate, hipStream_t s) {
+  int nb; const int rpb = rows_per_block(M, &nb);
+  if (dtype == 1) hipLaunchKernelGGL((bn_stats_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, s, (bf16_t*)dy, M, C, dy_cs, slab, rpb,
+                                     (const float*)nullptr, (const bf16_t*)y, y_cs);
+  else            hipLaunchKernelGGL((bn_stats_kernel<float, true>), dim3(nb), dim3(256), 0, s, (float*)dy, M, C, dy_cs, slab, rpb,
+                                     (const float*)nullptr, (const float*)y, y_cs);
+  int rows = nb;
   const float* sl = shrink_slab(slab, &rows, C, scratch, s);
   hipLaunchKernelGGL(slab_colsum_finalize_kernel, dim3((C + 63) / 64), dim3(FIN_T), 0, s, sl, rows, C, out, accumulate);
   return dpa_launch_rc();

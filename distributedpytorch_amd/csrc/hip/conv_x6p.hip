@@ -59,7 +59,9 @@ DPA_API int dpa_split3_planes(const float* w, void* out, long long n, hipStream_
 // Every conv layer needs, once per step, its filter as three bf16 planes (fprop), the transposed filter [C][RS][K]
 // (dgrad) and that one's planes: two or three tiny launches per layer (DenseNet-121: 359 launches and 1.2 ms of a 25 ms
 // step at batch 64).  This kernel does all of them in ONE launch from a device-side segment table.
-// One thread per 8 consecutive OUTPUT elements; a segment is found by binary search over the first chunk of each segment.
+// One thread per 8 consecutive OUTPUT elements; a block of 256 chunks lies inside one segment (segments start at multiples
+// of 256 chunks), found by binary search over the first chunk of each segment.
+// transposed: 0 = planes of the filter as it is, 1 = transpose by strided gather, 2 = transpose through an LDS tile.
 struct WPrepSeg {
   long long first_chunk;   // index of this segment's first 8-element chunk in the launch
   long long n;             // elements (a multiple of 8)
@@ -70,39 +72,67 @@ struct WPrepSeg {
 };
 template <typename T>
 __global__ void __launch_bounds__(256) weight_prep_kernel(const WPrepSeg* __restrict__ segs, int nsegs, long long total_chunks) {
-  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (g >= total_chunks) return;
+  // every segment starts at a multiple of 256 chunks, so a block lies inside ONE segment (found by its first thread's chunk)
+  __shared__ float tile[64][33];
+  const long long g0 = (long long)blockIdx.x * 256;
   int lo = 0, hi = nsegs - 1;
-  while (lo < hi) {                          // last segment whose first_chunk <= g
+  while (lo < hi) {                          // last segment whose first_chunk <= g0 (block-uniform)
     const int mid = (lo + hi + 1) >> 1;
-    if (segs[mid].first_chunk <= g) lo = mid; else hi = mid - 1;
+    if (segs[mid].first_chunk <= g0) lo = mid; else hi = mid - 1;
   }
   const WPrepSeg sg = segs[lo];
-  const long long i0 = (g - sg.first_chunk) * 8;
+  const int t = threadIdx.x;
+  const long long lc0 = g0 - sg.first_chunk;         // first local chunk of this block
+  if (lc0 * 8 >= sg.n) return;                       // padding between segments (block-uniform)
   const T* __restrict__ src = reinterpret_cast<const T*>(sg.src);
   alignas(16) T v[8];
-  if (sg.transposed) {
-    // output order [c][rs][k]: k runs over 8 consecutive filters (K % 8 == 0), the source stride between them is RS * C
-    const int k = (int)(i0 % sg.K);
-    const long long t = i0 / sg.K;
-    const int rs = (int)(t % sg.RS), c = (int)(t / sg.RS);
-    const T* s0 = src + ((long long)k * sg.RS + rs) * sg.C + c;
-    const long long st = (long long)sg.RS * sg.C;
+  long long i0;                                      // first of this thread's 8 consecutive OUTPUT elements
+  if (sg.transposed == 2) {
+    // tiled transpose (fp32, K % 64 == 0, C % 32 == 0): the block owns 64 filters x 32 channels of one tap.  Coalesced
+    // reads along c, LDS, coalesced 32-byte writes along k.  (The gather below reads 4 bytes per 128-byte line: 451 us
+    // for AlexNet's 58 M fully-connected weights.)
+    const int tilesC = sg.C / 32, tilesK = sg.K / 64;
+    const long long tl = lc0 >> 8;                   // tile index: k-tile fastest, then c-tile, then tap
+    const int tk = (int)(tl % tilesK);
+    const long long r1 = tl / tilesK;
+    const int tc = (int)(r1 % tilesC), rs = (int)(r1 / tilesC);
+    const float* fsrc = reinterpret_cast<const float*>(sg.src);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = s0[e * st];
-    if (sg.dst) {
-      T* d = reinterpret_cast<T*>(sg.dst) + i0;
-      if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(v);
-      }
+    for (int p = 0; p < 2; ++p) {
+      const int kr = p * 32 + (t >> 3), c4 = (t & 7) * 4;
+      const float4 x = *reinterpret_cast<const float4*>(fsrc + ((long long)(tk * 64 + kr) * sg.RS + rs) * sg.C + tc * 32 + c4);
+      tile[kr][c4] = x.x; tile[kr][c4 + 1] = x.y; tile[kr][c4 + 2] = x.z; tile[kr][c4 + 3] = x.w;
     }
+    __syncthreads();
+    const int c = t >> 3, k8 = (t & 7) * 8;
+    float* fv = reinterpret_cast<float*>(v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fv[e] = tile[k8 + e][c];
+    i0 = ((long long)(tc * 32 + c) * sg.RS + rs) * sg.K + tk * 64 + k8;
   } else {
-    if constexpr (sizeof(T) == 4) {
+    i0 = (lc0 + t) * 8;
+    if (i0 >= sg.n) return;
+    if (sg.transposed) {
+      // output order [c][rs][k]: k runs over 8 consecutive filters (K % 8 == 0), the source stride between them is RS * C
+      const int k = (int)(i0 % sg.K);
+      const long long r1 = i0 / sg.K;
+      const int rs = (int)(r1 % sg.RS), c = (int)(r1 / sg.RS);
+      const T* s0 = src + ((long long)k * sg.RS + rs) * sg.C + c;
+      const long long st = (long long)sg.RS * sg.C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = s0[e * st];
+    } else if constexpr (sizeof(T) == 4) {
       *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src + i0);
       *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + i0 + 4);
+    }
+  }
+  if (sg.transposed && sg.dst) {
+    T* d = reinterpret_cast<T*>(sg.dst) + i0;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(v);
     }
   }
   if constexpr (sizeof(T) == 4) {
@@ -621,6 +651,13 @@ bool dpa_x6p_eligible(const ConvParams& p) {
   // general kernel's split-K / small tiles, and dC <= 32 (DenseNet growth convs) its 128 x 32 tile.
   return enabled && p.wgt3 && (p.sC % 32 == 0) && ntaps >= 1 && ntaps <= 32 && !p.no_uni && p.Kg >= 32 * min_kt && p.dC > 32 &&
          x6p_tiles(p, x6p_narrow(p)) >= min_tiles;
+}
+// Could a problem with M rows and dC output columns take this kernel at all (are filter planes worth preparing)?  The
+// per-launch decision (dpa_x6p_eligible) looks at more, this is its size part: skinny problems - Linear layers at small
+// batches - never qualify, and their planes would be most of the per-step weight preparation.
+DPA_API int dpa_x6p_plausible(long long M, int dC) {
+  ConvParams q{}; q.M = (int)(M > 0x7fffffffLL ? 0x7fffffffLL : M); q.dC = dC;
+  return dC > 32 && x6p_tiles(q, x6p_narrow(q)) >= dpa_x6p_min_tiles(-1);
 }
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {

@@ -96,10 +96,11 @@ class Conv2d:
             setattr(self, which, buf)
         return ops.split3_planes(w, buf)
 
-    def _fwd_planes(self, ctx, w):
+    def _fwd_planes(self, ctx, w, m_rows):
         """The filter planes of this forward pass: from the batched per-step preparation (nn/wprep.py) when this pass ran
-        it, else through the per-layer kernel."""
-        if w.shape[3] % 32 or not ops.fp32_x6_active(ctx.cuda, w.dtype):
+        it, else through the per-layer kernel.  None when the pre-split kernel cannot be taken anyway (a problem of m_rows
+        output rows is too small for it: Linear layers at small batches, whose planes would be most of the preparation)."""
+        if w.shape[3] % 32 or not ops.fp32_x6_active(ctx.cuda, w.dtype) or not ops.x6p_plausible(m_rows, w.shape[0]):
             return None
         r = self.store.wprep.get(ctx, (self.w.index, "f"), self.w, (w.shape[0], 1, w.numel() // w.shape[0]), False, True)
         if r is not None:
@@ -121,10 +122,10 @@ class Conv2d:
         if self._as_gemm(x):      # whole-map 'valid' kernel = plain GEMM over the flattened (h, w, c) features
             w = w.view(w.shape[0], 1, 1, -1)
             ops.conv_fprop(x.view(n, 1, 1, -1), w, out, (1, 1), (0, 0), bias=bias, relu=relu,
-                           stats=stats, stats_shift=stats_shift, w3=self._fwd_planes(ctx, w))
+                           stats=stats, stats_shift=stats_shift, w3=self._fwd_planes(ctx, w, n))
         else:
             ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats, stats_shift=stats_shift,
-                           w3=self._fwd_planes(ctx, w))
+                           w3=self._fwd_planes(ctx, w, n * ho * wo))
         if stats is not None:
             self.last_stats_rows = ops.last_conv_stats_rows(ctx.cuda)
         return out
@@ -137,7 +138,7 @@ class Conv2d:
         return (self.ksize != (1, 1) and tuple(x.shape[1:3]) == self.ksize and self.padding == (0, 0)
                 and x.is_contiguous() and x.shape[3] == self.store.cview(self.w).shape[3])
 
-    def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor, last_use=False):
+    def backward_raw(self, ctx: Context, x: Act, dy: torch.Tensor, last_use=False, bias_done=False):
         """dy is the gradient w.r.t. the raw conv output (pre-activation).  Writes dW/db, accumulates dx.
         last_use: this dgrad is the LAST contribution to x.grad (every other consumer of x ran later in the forward
         pass) - it may then finish x's gradient for the BatchNorm that produced x (see _dgrad)."""
@@ -155,7 +156,7 @@ class Conv2d:
             # backward), so it overlaps the MFMA-bound dgrads AND the memory-bound BatchNorm-backward kernels in between.
             tape = ctx.tape
             tape.join_side(max(BWD_LAG - 1, 0))
-            if self.b is not None:
+            if self.b is not None and not bias_done:
                 ops.colsum(dy, st.gview(self.b))      # (shares scratch with main-stream kernels: stays on the main stream)
             if self._ev is None:
                 self._ev = (torch.cuda.Event(), torch.cuda.Event())
@@ -171,7 +172,7 @@ class Conv2d:
         if self.trainable:
             if ctx.tape.side_pending:
                 ctx.tape.join_side(0)        # this wgrad runs on the main stream and shares the split-K workspace
-            self._wgrad(ctx, x, dy)
+            self._wgrad(ctx, x, dy, bias=not bias_done)
             self._ready(ctx)
         if x.needs_grad:
             self._dgrad(ctx, x, dy, last_use)
@@ -224,7 +225,8 @@ class Conv2d:
         if gemm:
             w = w.view(w.shape[0], 1, 1, -1)
         k, r, s, c = w.shape
-        want_planes = k % 32 == 0 and ops.fp32_x6_active(ctx.cuda, w.dtype)
+        rows = x.data.shape[0] if gemm else x.data.shape[0] * x.data.shape[1] * x.data.shape[2]
+        want_planes = k % 32 == 0 and ops.fp32_x6_active(ctx.cuda, w.dtype) and ops.x6p_plausible(rows, c)
         prep = self.store.wprep.get(ctx, (self.w.index, "t"), self.w, (k, r * s, c), True, want_planes)
         if prep is not None:          # transposed filter (+ planes) made by this pass's batched preparation (nn/wprep.py)
             wt, wt3 = prep["dst"].view(c, r, s, k), prep["pl"]
@@ -233,7 +235,7 @@ class Conv2d:
             if self._wt is None or self._wt.shape != (c, r, s, k):
                 self._wt = torch.empty((c, r, s, k), device=w.device, dtype=w.dtype)
             ops.transpose_krsc(w, self._wt)
-            wt, wt3 = self._wt, self._planes(ctx, self._wt, "_wt3")
+            wt, wt3 = self._wt, (self._planes(ctx, self._wt, "_wt3") if want_planes else None)
         stride, padding = ((1, 1), (0, 0)) if gemm else (self.stride, self.padding)
         flat = (lambda t: t.view(t.shape[0], 1, 1, -1)) if gemm else (lambda t: t)
         fuse = self._bn_fusion(ctx, x, gemm) if last_use else None
@@ -252,9 +254,13 @@ class Conv2d:
             def bw():
                 dy = y.grad
                 y.grad = None
-                if relu:
+                bias_done = False
+                if relu and self.b is not None and self.trainable:
+                    ops.relu_bwd_colsum(dy, y.data, self.store.gview(self.b))    # mask + bias gradient in one pass over dy
+                    bias_done = True
+                elif relu:
                     ops.relu_bwd(dy, y.data)
-                self.backward_raw(ctx, x, dy, last_use=last_use)
+                self.backward_raw(ctx, x, dy, last_use=last_use, bias_done=bias_done)
             ctx.tape.push(bw)
         return y
 

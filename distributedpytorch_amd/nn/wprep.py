@@ -43,14 +43,18 @@ class WeightPrep:
         if getattr(ctx, "wprep", None) is not self:
             return None
         r = self.req.get(key)
-        if r is not None and key in self.ready and (r["K"], r["RS"], r["C"], r["planes"]) == (*krsc, planes):
-            return r
+        same = r is not None and (r["K"], r["RS"], r["C"]) == tuple(krsc)
+        if same and (r["planes"] or not planes):        # planes are sticky: a pass that does not need them (a smaller
+            if key in self.ready:                       # last batch) must not trigger a rebuild of the table
+                return r
+            return None
         if r is None:
             self.order.append(key)
-        if r is None or (r["K"], r["RS"], r["C"], r["planes"]) != (*krsc, planes):
-            self.req[key] = dict(spec=spec, K=krsc[0], RS=krsc[1], C=krsc[2], transposed=transposed, planes=planes, dst=None, pl=None)
-            self.ready.discard(key)
-            self.dirty = True
+        keep = r if same else None                      # upgrade (planes wanted now): keep the transposed buffer
+        self.req[key] = dict(spec=spec, K=krsc[0], RS=krsc[1], C=krsc[2], transposed=transposed, planes=planes,
+                             dst=keep["dst"] if keep else None, pl=None)
+        self.ready.discard(key)
+        self.dirty = True
         return None
 
     # ------------------------------------------------------------------ step side
@@ -82,10 +86,13 @@ class WeightPrep:
             if r["planes"] and r["pl"] is None:
                 r["pl"] = torch.empty(3 * n, device=dev, dtype=torch.bfloat16)
             src = arena.data_ptr() + r["spec"].offset * esz
+            mode = 0
+            if r["transposed"]:       # 2: through an LDS tile (fp32, 64 x 32 tiles), 1: strided gather
+                mode = 2 if (esz == 4 and r["K"] % 64 == 0 and r["C"] % 32 == 0) else 1
             rows.append([chunk, n, src, r["dst"].data_ptr() if r["dst"] is not None else 0,
                          r["pl"].data_ptr() if r["pl"] is not None else 0,
-                         r["K"] | (r["RS"] << 32), r["C"] | ((1 if r["transposed"] else 0) << 32)])
-            chunk += n // 8
+                         r["K"] | (r["RS"] << 32), r["C"] | (mode << 32)])
+            chunk += (n // 8 + 255) // 256 * 256          # a block of 256 chunks never straddles two segments
         if self.table is not None:
             self._old_tables.append(self.table)        # a captured hipGraph may still point at it
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None

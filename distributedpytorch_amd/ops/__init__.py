@@ -2,6 +2,8 @@
 plain-PyTorch reference (ref_ops, also the test oracle).  The first positional argument decides."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import ref_ops
@@ -21,7 +23,7 @@ def _hip():
 _TENSOR_OPS = [
     "conv_fprop", "conv_dgrad", "conv_wgrad", "transpose_krsc",
     "bn_stats", "bn_finalize", "bn_eval_coeffs", "bn_apply", "bn_bwd_reduce", "bn_bwd_dx", "bn_bwd_from_slab",
-    "relu_fwd", "relu_bwd", "add", "copy", "dropout", "rng_advance", "colsum",
+    "relu_fwd", "relu_bwd", "relu_bwd_colsum", "add", "copy", "dropout", "rng_advance", "colsum",
     "maxpool_fwd", "maxpool_bwd", "avgpool_fwd", "avgpool_bwd",
     "ce_loss", "adam_step", "sgd_step", "advance_step", "cast", "augment_mnist",
 ]
@@ -72,6 +74,13 @@ def fp32_x6_active(cuda, dtype):
         return False
     from . import native
     return native.get_fp32_mode() == "x6"
+
+
+def x6p_plausible(m_rows, cout):
+    """Could a convolution with m_rows output rows and cout output channels take the pre-split fp32 kernel (size part of
+    its eligibility rule, csrc/hip/conv_x6p.hip)?  GPU only - callers have checked fp32_x6_active."""
+    from . import native
+    return bool(native.hip_lib().dpa_x6p_plausible(ctypes.c_longlong(int(m_rows)), ctypes.c_int(int(cout))))
 
 
 def bn_reduce_rows(n_pixels, stride, cuda):

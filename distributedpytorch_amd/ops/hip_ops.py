@@ -173,6 +173,20 @@ def colsum(x, out, accumulate=False):
     return out
 
 
+def relu_bwd_colsum(dy, y, out, accumulate=False):
+    """dy *= (y > 0) in place and out (+)= the column sums of the masked dy: ReLU backward + bias gradient in one pass."""
+    m, c, cs = _mc(dy)
+    if m <= 2048:
+        relu_bwd(dy, y)
+        return colsum(dy, out, accumulate)
+    rows = bn_slab_rows(m)
+    slab = _scratch_f32(dy.device, rows * 2 * c, "colsum_slab")
+    scratch = _scratch_f32(dy.device, ROWS_L2 * 2 * c, "bn")
+    _lib().dpa_relu_bwd_colsum(ptr(dy), cs, ptr(y), _mc(y)[2], _DT[dy.dtype], I64(m), c, ptr(slab), ptr(scratch), ptr(out),
+                               int(accumulate), stream_ptr())
+    return out
+
+
 # ----------------------------------------------------------------------------------------- pooling
 from .ref_ops import pool_out_size  # noqa: E402,F401  (pure arithmetic)
 

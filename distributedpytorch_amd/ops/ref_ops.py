@@ -262,6 +262,11 @@ def colsum(x, out, accumulate=False):
     return out
 
 
+def relu_bwd_colsum(dy, y, out, accumulate=False):
+    relu_bwd(dy, y)
+    return colsum(dy, out, accumulate)
+
+
 # ----------------------------------------------------------------------------------------- pooling
 def pool_out_size(h, k, s, p, ceil_mode=False):
     if ceil_mode:

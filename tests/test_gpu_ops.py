@@ -216,10 +216,18 @@ def test_elementwise_and_colsum(dtype):
         big = _rand((4, 40, 40, 16), dtype, 4).to(dev)
         cs2 = torch.zeros(16, device=dev)
         O.colsum(big, cs2)
+        # ReLU backward + bias gradient in one pass (tall: the fused kernel; short: the two separate ones), sliced views
+        yb = _rand((4, 40, 40, 24), dtype, 6).to(dev)
+        gb = _rand((4, 40, 40, 24), dtype, 7).to(dev)
+        cs3 = torch.ones(16, device=dev)
+        O.relu_bwd_colsum(gb[..., 8:], yb[..., 8:], cs3, accumulate=True)
+        ys, gs = _rand((2, 5, 5, 16), dtype, 8).to(dev), _rand((2, 5, 5, 16), dtype, 9).to(dev)
+        cs4 = torch.zeros(16, device=dev)
+        O.relu_bwd_colsum(gs, ys, cs4)
         w = _rand((24, 3, 3, 16), dtype, 5).to(dev)
         wt = torch.empty(16, 3, 3, 24, device=dev, dtype=dtype)
         O.transpose_krsc(w, wt)
-        res[name] = [t.float().cpu() for t in (s, r, g, cs, cs2, wt)]
+        res[name] = [t.float().cpu() for t in (s, r, g, cs, cs2, wt, gb, cs3, gs, cs4)]
     rtol, atol = _tol(dtype)
     for x, y in zip(res["hip"], res["ref"]):
         torch.testing.assert_close(x, y, rtol=rtol, atol=atol * 20)
