@@ -628,12 +628,14 @@ DPA_API int dpa_x6p_min_tiles(int v) {
 static long long x6p_tiles(const ConvParams& p, bool narrow) {
   return (long long)((p.M + 127) / 128) * ((p.dC + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
 }
-// which: 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_TALL_MIN (default 512).  v >= 0 sets the knob and returns
+// which: 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_TALL_MIN (default 512), 3 = DPA_X6P_TALL (default 0: the
+// 256-row tile is an experiment that lost).  v >= 0 sets the knob and returns
 // the previous value (the kernel tests steer small shapes to each variant with it); v < 0 only reads it.
 DPA_API int dpa_x6p_knob(int which, int v) {
-  static int cur[3] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
-                          [] { const char* e = getenv("DPA_X6P_TALL_MIN"); return e ? atoi(e) : 512; }()};
-  if (which < 1 || which > 2) return -1;
+  static int cur[4] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
+                          [] { const char* e = getenv("DPA_X6P_TALL_MIN"); return e ? atoi(e) : 512; }(),
+                          [] { const char* e = getenv("DPA_X6P_TALL"); return e ? atoi(e) : 0; }()};
+  if (which < 1 || which > 3) return -1;
   const int prev = cur[which];
   if (v >= 0) cur[which] = v;
   return prev;
@@ -665,7 +667,7 @@ int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   static const int apl_tn = [] { const char* e = getenv("DPA_X6PP_TN"); return e ? atoi(e) : 8; }();      // experiment: tile width with src3
   // 256-row tile (one block per CU): opt-in experiment (DPA_X6P_TALL=1, for problems with at least DPA_X6P_TALL_MIN such
   // tiles) - measured 10-15 % SLOWER than the 128-row tile on every ResNet-50 layer (profiles/r2_x6p_tall_tile.txt)
-  static const int tall = [] { const char* e = getenv("DPA_X6P_TALL"); return e ? atoi(e) : 0; }();
+  const int tall = dpa_x6p_knob(3, -1);
   const int tall_min = dpa_x6p_knob(2, -1);
   const long long tall_tiles = (long long)((p.M + 255) / 256) * ((p.dC + 127) / 128);
   if (x6p_narrow(p) || (p.src3 && apl_tn == 4)) x6p_launch<4, 4, 16>(p, dgrad, s);

@@ -140,14 +140,14 @@ PRESPLIT_SHAPES = [
 @pytest.fixture(params=["narrow", "wide", "tall"])
 def x6p_variant(request):
     """Steer the (small) test problems to each tile variant of the pre-split kernel: 128 x 64, 128 x 128 (two blocks per CU)
-    and 256 x 128 (one block per CU); production picks by problem size (DPA_X6P_NARROW_BELOW / DPA_X6P_TALL_MIN)."""
+    and 256 x 128 (one block per CU, an opt-in experiment); production picks by problem size (DPA_X6P_NARROW_BELOW)."""
     from distributedpytorch_amd.ops import native
     lib = native.hip_lib()
     big = 1 << 30
-    narrow_below, tall_min = {"narrow": (big, big), "wide": (0, big), "tall": (0, 1)}[request.param]
-    prev = lib.dpa_x6p_knob(1, narrow_below), lib.dpa_x6p_knob(2, tall_min)
+    narrow_below, tall_min, tall = {"narrow": (big, big, 0), "wide": (0, big, 0), "tall": (0, 1, 1)}[request.param]
+    prev = lib.dpa_x6p_knob(1, narrow_below), lib.dpa_x6p_knob(2, tall_min), lib.dpa_x6p_knob(3, tall)
     yield request.param
-    lib.dpa_x6p_knob(1, prev[0]); lib.dpa_x6p_knob(2, prev[1])
+    lib.dpa_x6p_knob(1, prev[0]); lib.dpa_x6p_knob(2, prev[1]); lib.dpa_x6p_knob(3, prev[2])
 
 
 @pytest.mark.parametrize("shape", PRESPLIT_SHAPES)
