@@ -64,6 +64,10 @@ struct ConvParams {
   // ("producer-side split"): [3][sN*sH*sW*s_cs] bf16.  The x6p kernel then has no VALU split at all.  Not used by the framework.
   const void* src3;
   long long src3_plane;
+  // Per-output-channel multiplier applied to the accumulator BEFORE the bias: out = acc * oscale[c] + bias[c] (+ addend)
+  // (ReLU).  With oscale = gamma / sqrt(running_var + eps) and bias = beta - running_mean * oscale this is an inference
+  // BatchNorm folded into the convolution (fprop only; null = 1).
+  const float* oscale;
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;

@@ -334,6 +334,17 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
     const int col = n0 + wn * WCOLS + j * 16 + fr;
     bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
   }
+  if (!SPLIT && p.oscale) {                    // folded inference BatchNorm: acc * scale[col] before the bias
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WCOLS + j * 16 + fr;
+      const float sc = col < p.dC ? p.oscale[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] *= sc;
+    }
+  }
   float cj[TN];                                // statistics shift of this lane's columns
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -483,7 +494,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p) 
     const int m = (int)(idx / chunks), col = (int)(idx - (long long)m * chunks) * VEC;
     float v[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = p.bias ? p.bias[col + e] : 0.f;
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
     for (int s = 0; s < p.splitK; ++s) {
       const float* src = p.ws + ((size_t)s * p.M + m) * p.dC + col;
 #pragma unroll
@@ -492,6 +503,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvParams p) 
         v[e] += t.x; v[e + 1] += t.y; v[e + 2] += t.z; v[e + 3] += t.w;
       }
     }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = v[e] * (p.oscale ? p.oscale[col + e] : 1.f) + (p.bias ? p.bias[col + e] : 0.f);
     const size_t off = (size_t)m * (size_t)p.d_cs + (size_t)(p.d_co + col);
     if (addend) {
       Vec16<T> av; av.load(addend + off);

@@ -534,6 +534,17 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
       bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
       cj[j] = (p.stats && p.stats_shift && col < p.dC) ? p.stats_shift[col] : 0.f;
     }
+    if (!DGRAD && p.oscale) {                  // folded inference BatchNorm: acc * scale[col] before the bias
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + j * 16 + fr;
+        const float sc = col < p.dC ? p.oscale[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] *= sc;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -20,6 +20,9 @@ from .engine import BWD_LAG, Act, Context, ParamStore, accumulate_grad, pad_to, 
 # fewest GFLOP of a weight gradient that is worth the side stream's fork / join events (profiles/r2_side_stream_threshold.txt)
 SIDE_MIN_GFLOP = float(os.environ.get("DPA_BWD_SIDE_MIN_GFLOP", "40"))
 
+# DPA_FOLD_EVAL_BN=0: evaluation keeps the separate BatchNorm-apply pass (A/B switch)
+_FOLD_EVAL_BN = os.environ.get("DPA_FOLD_EVAL_BN", "1") != "0"
+
 # DPA_FUSE_BN_BWD=0: never fuse the BatchNorm-backward reduction into the dgrad epilogue (A/B switch)
 _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
 
@@ -112,20 +115,27 @@ class Conv2d:
         return (ops.out_size(h, self.ksize[0], self.stride[0], self.padding[0]),
                 ops.out_size(w, self.ksize[1], self.stride[1], self.padding[1]))
 
-    def forward_raw(self, ctx: Context, x: torch.Tensor, out=None, relu=False, stats=None, stats_shift=None):
+    def forward_raw(self, ctx: Context, x: torch.Tensor, out=None, relu=False, stats=None, stats_shift=None, fold=None):
+        """fold = (scale, shift, addend): out = conv * scale[c] + shift[c] (+ addend) - an inference BatchNorm (and the
+        residual connection) folded into the epilogue; only for convolutions without a bias of their own."""
         n, h, w, _ = x.shape
         ho, wo = self.out_hw(h, w)
         if out is None:
             out = ctx.empty((n, ho, wo, pad_to(self.cout)))
         bias = self.store.view(self.b) if self.b is not None else None
+        kw = {}
+        if fold is not None:
+            assert bias is None
+            bias = fold[1]
+            kw = dict(oscale=fold[0], addend=fold[2])
         w = self.store.cview(self.w)
         if self._as_gemm(x):      # whole-map 'valid' kernel = plain GEMM over the flattened (h, w, c) features
             w = w.view(w.shape[0], 1, 1, -1)
             ops.conv_fprop(x.view(n, 1, 1, -1), w, out, (1, 1), (0, 0), bias=bias, relu=relu,
-                           stats=stats, stats_shift=stats_shift, w3=self._fwd_planes(ctx, w, n))
+                           stats=stats, stats_shift=stats_shift, w3=self._fwd_planes(ctx, w, n), **kw)
         else:
             ops.conv_fprop(x, w, out, self.stride, self.padding, bias=bias, relu=relu, stats=stats, stats_shift=stats_shift,
-                           w3=self._fwd_planes(ctx, w, n * ho * wo))
+                           w3=self._fwd_planes(ctx, w, n * ho * wo), **kw)
         if stats is not None:
             self.last_stats_rows = ops.last_conv_stats_rows(ctx.cuda)
         return out
@@ -350,6 +360,15 @@ class ConvBNAct:
         n, h, w, _ = x.data.shape
         ho, wo = conv.out_hw(h, w)
         m, cp = n * ho * wo, pad_to(conv.cout)
+        if _FOLD_EVAL_BN and not ctx.training and not ctx.grad_enabled and conv.b is None:
+            # inference: the BatchNorm is a per-channel affine map of the conv output - applied in the conv epilogue together
+            # with the residual connection and the ReLU, so evaluation runs no BatchNorm kernel over the activations at all
+            a = bn.coeffs(ctx, None, m)
+            if out is None:
+                out = ctx.empty((n, ho, wo, cp))
+            conv.forward_raw(ctx, x.data, out=out, relu=relu,
+                             fold=(a[2], a[3], None if residual is None else residual.data))
+            return Act(out, False)
         slab = _stats_slab(ctx, m, cp, True) if ctx.training else None
         z = conv.forward_raw(ctx, x.data, stats=slab, stats_shift=bn.stat_shift(ctx))
         if slab is not None:

@@ -52,9 +52,11 @@ def weight_prep(table, nsegs, total_chunks, dtype):
                         native.stream_ptr())
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None, _nol=None, _x3=None):
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None, _nol=None, _x3=None,
+               oscale=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats: fp32 [rows, 2, Cout] slab written with per-block
-    (sum, sumsq) of the stored outputs minus the per-channel `stats_shift` (0 if None); rows = stats_rows(M, Cout)."""
+    (sum, sumsq) of the stored outputs minus the per-channel `stats_shift` (0 if None); rows = stats_rows(M, Cout).
+    oscale: fp32 per-output-channel multiplier applied to the accumulator before the bias (folded inference BatchNorm)."""
     lib = native.hip_lib()
     sh, sw = stride
     ph, pw = pad
@@ -64,6 +66,7 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     p.stats = native.ptr(stats)
     p.addend = native.ptr(addend)
     p.stats_shift = native.ptr(stats_shift)
+    p.oscale = native.ptr(oscale)
     p.wgt3, p.wgt3_plane = native.ptr(w3), w.numel()
     if _x3 is not None:           # experiment only (scripts/bench_x6pp.py): the activation pre-split into planes too
         p.src3, p.src3_plane = VP(_x3.data_ptr()), x.numel()

@@ -29,10 +29,13 @@ def stats_rows(m, cout):
     return 1
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None):
-    out = F.conv2d(_nchw(x).float(), _nchw(w).float(), None if bias is None else bias.float()[: w.shape[0]],
-                   stride=stride, padding=pad)
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None, oscale=None):
+    out = F.conv2d(_nchw(x).float(), _nchw(w).float(), None, stride=stride, padding=pad)
     out = _nhwc(out)
+    if oscale is not None:
+        out = out * oscale.float()[: w.shape[0]]
+    if bias is not None:
+        out = out + bias.float()[: w.shape[0]]
     stored = out.to(y.dtype)
     if stats is not None:
         sf = stored.float().reshape(-1, stored.shape[-1])

@@ -137,6 +137,34 @@ PRESPLIT_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128, 3, 1, 1), (2, 14, 14, 256, 1024, 1, 1, 0), (130, 1, 1, 512, 160, 1, 1, 0),
+                                   (2, 17, 13, 24, 40, 3, 2, 1)])
+def test_conv_fprop_output_scale_epilogue(shape, dtype, fp32_mode):
+    """ConvParams::oscale: out = relu(conv * scale[c] + bias[c] + addend) - the inference BatchNorm folded into the epilogue -
+    in the pre-split kernel, the general kernel and its split-K reduction (the linear-shaped problem)."""
+    from distributedpytorch_amd.ops import hip_conv
+    if dtype == torch.bfloat16 and fp32_mode == "exact":
+        pytest.skip("the fp32 arithmetic mode does not affect the bf16 kernels")
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(K, k, k, C, device="cuda", generator=g) * (k * k * C) ** -0.5).to(dtype)
+    sc = torch.rand(K, device="cuda", generator=g) + 0.5
+    b = torch.randn(K, device="cuda", generator=g)
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    add = torch.randn(N, Ho, Wo, K, device="cuda", generator=g).to(dtype)
+    w3 = None
+    if dtype == torch.float32 and C % 32 == 0:
+        w3 = hip_conv.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
+    y = torch.full((N, Ho, Wo, K), float("nan"), device="cuda", dtype=dtype)
+    hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd), bias=b, relu=True, addend=add, w3=w3, oscale=sc)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride=s, padding=pd).permute(0, 2, 3, 1)
+    ref = (ref * sc + b + add.float()).clamp_min(0)
+    rtol, atol = _tol(dtype, k * k * C)
+    torch.testing.assert_close(y.float(), ref, rtol=rtol, atol=atol * 10)
+
+
 @pytest.fixture(params=["narrow", "wide", "tall"])
 def x6p_variant(request):
     """Steer the (small) test problems to each tile variant of the pre-split kernel: 128 x 64, 128 x 128 (two blocks per CU)

@@ -89,6 +89,29 @@ def test_batched_weight_prep_is_bitwise_the_per_layer_path(model, dtype, monkeyp
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("model,dtype", [("resnet", torch.float32), ("resnet50", torch.float32), ("inception", torch.float32),
+                                         ("resnet", torch.bfloat16)])
+def test_eval_batchnorm_folded_into_conv_epilogue(model, dtype, monkeypatch):
+    """Evaluation applies BatchNorm (+ residual + ReLU) in the conv epilogue (ConvParams::oscale) instead of a separate
+    pass over the activations: same logits as the unfolded path, after a few training steps so that the running statistics
+    and the affine parameters are not the initial ones."""
+    from distributedpytorch_amd.nn import layers
+    net, opt, dm = _make(dtype, model)
+    side = 299 if model == "inception" else 64
+    x, y = _batch(4, side, net.in_channels, dtype)
+    for _ in range(3):
+        dm.train_step(x, y)
+    net.eval()
+    outs = []
+    for fold in (True, False):
+        monkeypatch.setattr(layers, "_FOLD_EVAL_BN", fold)
+        _, out = net.forward(x)
+        outs.append((out[0] if isinstance(out, tuple) else out).data.float().clone())
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(outs[0], outs[1], **tol)
+
+
 @pytest.mark.parametrize("model", ["resnet", "alexnet"])
 def test_hipgraph_replay_matches_eager(model):
     dtype = torch.bfloat16
