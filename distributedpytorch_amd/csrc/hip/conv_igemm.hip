@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
     const int col = n0 + wn * WCOLS + j * 16 + fr;
     bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
   }
-  if (!SPLIT && p.oscale) {                    // folded inference BatchNorm: acc * scale[col] before the bias
+  if constexpr (!SPLIT && !DGRAD) if (p.oscale) {      // folded inference BatchNorm: acc * scale[col] before the bias
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WCOLS + j * 16 + fr;

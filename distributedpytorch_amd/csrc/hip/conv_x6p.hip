@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
       bj[j] = (p.bias && col < p.dC) ? p.bias[col] : 0.f;
       cj[j] = (p.stats && p.stats_shift && col < p.dC) ? p.stats_shift[col] : 0.f;
     }
-    if (!DGRAD && p.oscale) {                  // folded inference BatchNorm: acc * scale[col] before the bias
+    if constexpr (!DGRAD) if (p.oscale) {      // folded inference BatchNorm: acc * scale[col] before the bias
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + j * 16 + fr;
