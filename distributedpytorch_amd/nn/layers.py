@@ -213,9 +213,9 @@ class Conv2d:
                 and self.ksize[0] >= self.stride[0] and self.ksize[1] >= self.stride[1]):
             return None
         # measured on ResNet-50, batch 1024 (profiles/r2_bn_bwd_fusion.txt): fp32 -6.5 ms per step (the removed kernel:
-        # -17.6 ms, the dgrad epilogues: +12 ms - their reads are exposed at the end of each tile); in bf16 the removed
-        # kernel moves half the bytes and the step got 2.5 ms SLOWER, so bf16 keeps the separate reduction
-        if x.data.dtype != torch.float32 and os.environ.get("DPA_FUSE_BN_BWD") != "force":
+        # -17.6 ms, the dgrad epilogues: +12 ms - their reads are exposed at the end of each tile); bf16 -1.3 ms (92.9 ->
+        # 91.6 ms; it was +2.5 ms before the finalize kernels were rewritten).  DPA_FUSE_BN_BWD=fp32 keeps bf16 unfused.
+        if x.data.dtype != torch.float32 and os.environ.get("DPA_FUSE_BN_BWD") == "fp32":
             return None
         bn, z, mask_from_x = x.bn_src
         if z.shape != x.data.shape:
