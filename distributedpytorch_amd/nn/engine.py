@@ -327,7 +327,11 @@ _side_streams = {}
 # single stream leaves the GPU nearly idle): -1 % on the ResNet-50 step, measured A/B on one box (214.0 vs 216.3 ms).
 # Larger lags gain nothing (two MFMA-bound kernels share the matrix pipes; the memory-bound BatchNorm kernels do not get
 # co-scheduled with a kernel that fills VGPRs and LDS).
-DUAL_STREAM_BACKWARD = os.environ.get("DPA_BWD_STREAMS", "2") == "2"
+# OPT-IN since the end of round 2 (DPA_BWD_STREAMS=2): once the small dependent kernels had been made shorter (finalize
+# kernels, batched weight preparation) there was nothing left for the side stream to fill - four interleaved A/B pairs on
+# one box: 217.2 / 217.8 / 217.2 / 217.7 ms with it, 215.2 / 217.2 / 215.4 / 217.1 ms without
+# (profiles/r2_side_stream_threshold.txt) - and one stream is the simpler thing to run next to the collectives.
+DUAL_STREAM_BACKWARD = os.environ.get("DPA_BWD_STREAMS", "1") == "2"
 BWD_LAG = int(os.environ.get("DPA_BWD_LAG", "1"))
 
 
