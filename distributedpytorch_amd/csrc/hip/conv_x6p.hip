@@ -27,6 +27,15 @@
 
 __device__ uint4 dpa_zero_chunk_x6p[4];
 
+// LDS offset of 16-byte chunk `chunk` of row `row` of the fp32 activation tile (128-byte rows).  A ds_read_b128 is served
+// 16 lanes per cycle - lanes 8m..8m+7 together with lanes 8m+16..8m+23, i.e. rows fr = 8h..8h+7 of TWO neighbouring k
+// groups fq = 2p, 2p+1, whose chunks (2 fq + ks) differ in bit 1 (measured with scripts/micro/lds_conflict.hip: the
+// generic chunk ^ ((row >> 1) & 7) swizzle of conv_common.h puts the two k groups on the same banks - every activation
+// fragment read took 8 cycles instead of 4, 12 % of this kernel's LDS cycles).  So the row pair index t = (row >> 1) & 3
+// goes into chunk bits 0 and 2 and leaves bit 1 to fq: 16 distinct 16-byte bank groups per cycle.
+__device__ __forceinline__ int x6p_a_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
+__device__ __forceinline__ int x6p_a_off(int row, int chunk) { return row * 128 + ((chunk ^ x6p_a_swz(row)) << 4); }
+
 __device__ __forceinline__ void split3_frag(const uint4& lo, const uint4& hi, uint4 (&pl)[3]) {
   const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   uint32_t o[4][3];
@@ -188,7 +197,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
 
   // ---- A operand: this thread stages the chunk that lands in slot tid & 7 of rows (tid >> 3) + 32 i -------------------
   const int row0 = tid >> 3;
-  const int ck = (tid & 7) ^ ((row0 >> 1) & 7);
+  const int ck = (tid & 7) ^ x6p_a_swz(row0);      // (rows advance by 32 per pass: the swizzle is the same for every pass)
   const int ntaps = p.nR * p.nS;
   // (block-uniform) the short-reduction 1x1 layers spend as long in this prologue as in their two K-tiles
   const bool linear = ntaps == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.sH == p.dH && p.sW == p.dW;
@@ -437,7 +446,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
+            fa[ks][i] = *reinterpret_cast<const uint4*>(tA + x6p_a_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
         uint4 bp[TN][3];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -474,7 +483,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
+          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + x6p_a_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
       }
       uint4 bp[JH][3];
 #pragma unroll
