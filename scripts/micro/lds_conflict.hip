@@ -32,6 +32,25 @@ __global__ void __launch_bounds__(256) probe(unsigned* out, int iters) {
           const uint4 v = *reinterpret_cast<const uint4*>(smem + flip + lds_off(wave * 32 + i * 16 + fr, 2 * fq + ks));
           acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
         }
+    } else if (MODE == 7) {        // general kernel (conv_igemm.hip): chunk = 4 ks + fq, chunk ^ ((row >> 1) & 7)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(smem + flip + lds_off(wave * 32 + i * 16 + fr, 4 * ks + fq));
+          acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    } else if (MODE == 8 || MODE == 9 || MODE == 10) {
+      // grouping tests: distinct 16-byte segments exactly within a hypothesised group of 16 lanes, the same banks in every other group
+      int off;
+      if (MODE == 8) off = ((lane & 7) + 8 * ((lane >> 4) & 1)) * 16 + 256 * ((lane >> 3) & 1) + 512 * (lane >> 5);   // lanes 8m..8m+7 with 8m+16..8m+23
+      else if (MODE == 9) off = (lane & 15) * 16 + 256 * (lane >> 4);                                                   // lanes 16g..16g+15
+      else off = ((lane & 7) + 8 * (lane >> 5)) * 16 + 256 * ((lane >> 3) & 3);                                         // lanes 8m..8m+7 with 8m+32..8m+39
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + flip + off + r * 1024 + wave * 4096);
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+      }
     } else if (MODE == 6) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -74,6 +93,10 @@ int main() {
   hipLaunchKernelGGL(probe<4>, dim3(256), dim3(256), 40960, 0, out, iters);
   hipLaunchKernelGGL(probe<5>, dim3(256), dim3(256), 40960, 0, out, iters);
   hipLaunchKernelGGL(probe<6>, dim3(256), dim3(256), 40960, 0, out, iters);
+  hipLaunchKernelGGL(probe<7>, dim3(256), dim3(256), 40960, 0, out, iters);
+  hipLaunchKernelGGL(probe<8>, dim3(256), dim3(256), 40960, 0, out, iters);
+  hipLaunchKernelGGL(probe<9>, dim3(256), dim3(256), 40960, 0, out, iters);
+  hipLaunchKernelGGL(probe<10>, dim3(256), dim3(256), 40960, 0, out, iters);
   hipDeviceSynchronize();
   printf("done %s\n", hipGetErrorString(hipGetLastError()));
   return 0;
