@@ -593,10 +593,10 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   static const int policy = [] { const char* e = getenv("DPA_CONV_STAGING"); return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'g' ? 2 : 0)); }();
   constexpr int BKE = 8 * (16 / (int)sizeof(T));
   const int nkt = (p.Kg + BKE - 1) / BKE;
-  // (fp32 in x6 mode on the 256 x 64 tile: its register-staged variant only exists in exact fp32 arithmetic - it would
+  // (fp32 in x6 mode on the 256 x 64 / 128 x 32 tiles (WM = 4): their register-staged variant only exists in exact fp32 arithmetic - it would
   //  spill with the operand splits - so short reductions take the LDS-DMA x6 variant there too: the ResNet stem conv,
   //  7 K-tiles, 3.93 -> 2.77 ms at batch 1024)
-  const bool x6_tall_short = sizeof(T) == 4 && WM == 4 && TM == 4 && fp32_x6() && nkt >= 2;
+  const bool x6_tall_short = sizeof(T) == 4 && WM == 4 && fp32_x6() && nkt >= 2;
   const bool use_glds = policy == 2 || (policy == 0 && (nkt >= 8 || x6_tall_short));
   size_t lds = (size_t)(BM + BN) * 128 * (use_glds ? 2 : 1);
   size_t epi = (size_t)(4 * 16 * (TN * 16 + 4) + WM * 2 * BN) * 4;
