@@ -40,8 +40,6 @@ def test_conv_fprop_dgrad_wgrad(shape, dtype, fp32_mode):
     from distributedpytorch_amd.ops import hip_conv
     if dtype == torch.bfloat16 and fp32_mode == "exact":
         pytest.skip("the fp32 arithmetic mode does not affect the bf16 kernels")
-    if x6p_variant != "narrow" and not (dtype == torch.float32 and fp32_mode == "x6"):
-        pytest.skip("the tile variants exist in the pre-split fp32 kernel only")
     N, H, W, C, K, k, s, pd = shape
     g = torch.Generator(device="cuda").manual_seed(1234)
     x = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
@@ -254,6 +252,8 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
     from distributedpytorch_amd.ops import hip_conv
     if dtype == torch.bfloat16 and fp32_mode == "exact":
         pytest.skip("the fp32 arithmetic mode does not affect the bf16 kernels")
+    if x6p_variant != "narrow" and not (dtype == torch.float32 and fp32_mode == "x6"):
+        pytest.skip("the tile variants exist in the pre-split fp32 kernel only")
     N, H, W, C, K, k, s, pd = shape
     g = torch.Generator(device="cuda").manual_seed(99)
     Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
