@@ -386,6 +386,9 @@ static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_
                                                                           // operand splits are paid per staged element, and this
                                                                           // tile does 2.3x the MFMAs per element of 64 x 64)
   else if (p.Ng <= 64) wg_launch<T, 2, 2, 2, 2>(p, grad, workspace, s);   //  64 x  64
+  else if (p.K <= 32 && p.Ng % 192 == 0 && p.Ng % 256 != 0)
+                       wg_launch<T, 1, 4, 2, 3>(p, grad, workspace, s);   //  32 x 192: DenseNet growth convs (32 filters, 3x3 x 128):
+  else if (p.K <= 32)  wg_launch<T, 1, 4, 2, 4>(p, grad, workspace, s);   //  32 x 256  no MFMA rows spent on padding filters
   else if (p.K <= 64 && p.Ng % 192 == 0 && p.Ng % 256 != 0)
                        wg_launch<T, 1, 4, 4, 3>(p, grad, workspace, s);   //  64 x 192: 3x3 x 64 channels without padding
   else if (p.K <= 64)  wg_launch<T, 1, 4, 4, 4>(p, grad, workspace, s);   //  64 x 256: narrow Cout, all waves share the dy tile
@@ -403,7 +406,7 @@ DPA_API int dpa_conv_wgrad(WgradParams* p, float* grad, float* workspace, int dt
 }
 // upper bound on workspace floats for a layer: split <= 1024 tiles-worth, i.e. <= ~1024*BM*BN + K*Ng
 DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {
-  const int bm = (Ng <= 64 && K >= 256) ? 256 : ((Ng <= 64 || K <= 64) ? 64 : 128);
+  const int bm = (Ng <= 64 && K >= 256) ? 256 : ((Ng > 64 && K <= 32) ? 32 : ((Ng <= 64 || K <= 64) ? 64 : 128));
   const int bn = Ng <= 64 ? 64 : (K <= 64 ? ((Ng % 192 == 0 && Ng % 256 != 0) ? 192 : 256) : 128);
   const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bn - 1) / bn);
   long long split = (1024 + tiles - 1) / tiles;      // upper bound of what wg_launch may choose

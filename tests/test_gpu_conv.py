@@ -15,6 +15,9 @@ SHAPES = [
     (8, 7, 7, 512, 512, 3, 1, 1),
     (2, 32, 32, 8, 64, 7, 2, 3),       # stem (Cin padded to 8)
     (2, 56, 56, 64, 256, 1, 1, 0),     # bottleneck expand
+    (4, 28, 28, 128, 32, 3, 1, 1),     # DenseNet growth conv: 32 filters (wgrad 32 x 192 tile)
+    (2, 17, 17, 64, 24, 3, 1, 1),      # 24 filters, Ng = 576 (wgrad 32 x 192 tile with padded rows)
+    (2, 9, 9, 32, 32, 5, 1, 2),        # 32 filters, Ng = 800 (wgrad 32 x 256 tile)
     (3, 17, 13, 24, 40, 5, 1, 2),      # odd sizes, channels not multiples of the tile
     (2, 20, 20, 16, 48, 11, 4, 2),     # alexnet-like stem
     (64, 1, 1, 512, 16, 1, 1, 0),      # linear as 1x1 conv
