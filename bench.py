@@ -81,34 +81,91 @@ def main():
     return worker(args)
 
 
+def _supervisor_store(rank, world):
+    """Coordination between the per-rank SUPERVISORS (they never touch the GPU): a C++ TCP store on MASTER_PORT + 3,
+    hosted by rank 0's supervisor.  Through it every rank learns at once that SOME rank's attempt failed, kills its own
+    child and moves to the fallback together with the others - without it a rank whose native worker died early would sit
+    alone in the fallback's rendezvous while the others burn their collective timeouts.  None when it cannot be set up
+    (the supervisors then decide independently, as before)."""
+    if world <= 1:
+        return None
+    try:
+        from distributedpytorch_amd.parallel.store import TCPStore
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29511")) + 3
+        st = TCPStore(addr, port, is_master=(rank == 0), timeout_s=float(os.environ.get("DPA_BENCH_SUPERVISOR_WAIT_S", "60")))
+        st.announce_and_wait(rank, world, tag="sup")
+        return st
+    except Exception as exc:        # noqa: BLE001 - coordination is an optimisation, not a requirement
+        print(f"[bench rank {rank}] supervisor store unavailable ({exc!r}); deciding the fallback alone", file=sys.stderr, flush=True)
+        return None
+
+
 def supervise(args):
-    """Run the measurement in child processes: native communicator first, the torch process group as fallback."""
+    """Run the measurement in child processes: native communicator first, the torch process group as fallback.  An
+    attempt counts only if EVERY rank's child succeeded; rank 0's JSON line is held back until that is known, so a job
+    never prints a number from an attempt some rank did not finish."""
     import signal
     import subprocess
     attempts = [args.comm] + (["torch"] if args.comm == "native" and os.environ.get("DPA_BENCH_NO_FALLBACK", "0") != "1" else [])
     argv = [a for a in sys.argv[1:]]
-    rank = os.environ.get("RANK", "0")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    sup = _supervisor_store(rank, world)
+    stub = os.environ.get("DPA_BENCH_STUB_WORKER")          # tests/test_bench_supervisor_cpu.py: a stand-in for the GPU worker
     rc = 1
-    for i, backend in enumerate(attempts):
-        limit = float(os.environ.get("DPA_BENCH_ATTEMPT_S", "270"))
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--worker", "--comm", backend]
-        env = dict(os.environ, DPA_BENCH_ATTEMPT=str(i))
-        p = subprocess.Popen(cmd, env=env, start_new_session=True)
-        try:
-            rc = p.wait(timeout=limit)
-        except subprocess.TimeoutExpired:
+    try:
+        for i, backend in enumerate(attempts):
+            limit = float(os.environ.get("DPA_BENCH_ATTEMPT_S", "270"))
+            cmd = [sys.executable, stub or os.path.abspath(__file__)] + argv + ["--worker", "--comm", backend]
+            env = dict(os.environ, DPA_BENCH_ATTEMPT=str(i))
+            p = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE, text=True)
+            t0 = time.time()
+            why = ""
+            while True:
+                try:
+                    rc = p.wait(timeout=0.25)
+                    break
+                except subprocess.TimeoutExpired:
+                    pass
+                if time.time() - t0 > limit:
+                    why, rc = f"exceeded {limit:.0f} s", 124
+                elif sup is not None and sup.check(f"fail/{i}"):
+                    why, rc = "another rank's attempt failed", 125
+                if why:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)        # exactly the process group started above
+                    except ProcessLookupError:
+                        pass
+                    p.wait()
+                    break
+            out = p.stdout.read() if p.stdout else ""
+            if sup is not None:
+                # agree on the attempt's outcome: failed as soon as anyone says so, succeeded when everyone says so
+                sup.set(f"fail/{i}" if rc else f"ok/{i}/{rank}", str(rc).encode())
+                deadline = time.time() + limit
+                while rc == 0 and time.time() < deadline:
+                    if sup.check(f"fail/{i}"):
+                        why, rc = "another rank's attempt failed", 125
+                    elif all(sup.check(f"ok/{i}/{r}") for r in range(world)):
+                        break
+                    else:
+                        time.sleep(0.05)
+            if rc == 0:
+                sys.stdout.write(out)
+                sys.stdout.flush()
+                return 0
+            if i + 1 < len(attempts):
+                print(f"[bench rank {rank}] comm backend '{backend}' failed (exit {rc}{': ' + why if why else ''}); re-running in a "
+                      f"fresh process with '{attempts[i + 1]}'", file=sys.stderr, flush=True)
+        return rc if rc else 1
+    finally:
+        if sup is not None:
             try:
-                os.killpg(p.pid, signal.SIGKILL)        # exactly the process group started above
-            except ProcessLookupError:
+                sup.barrier(rank, world, "sup_done", timeout_s=20)     # nobody closes the store while others still poll it
+            except Exception:       # noqa: BLE001
                 pass
-            p.wait()
-            rc = 124
-        if rc == 0:
-            return 0
-        if i + 1 < len(attempts):
-            print(f"[bench rank {rank}] comm backend '{backend}' failed (exit {rc}); re-running in a fresh process with "
-                  f"'{attempts[i + 1]}'", file=sys.stderr, flush=True)
-    return rc if rc else 1
+            sup.close()
 
 
 def worker(args):
@@ -147,6 +204,11 @@ def worker(args):
                                        rendezvous_timeout_s=120.0, create_for_single_rank=True)
     elif world > 1 or force:
         comm.init_process_group(rank, world, device)
+    # Known-answer check of the data plane BEFORE anything is timed: every rank contributes rank+1 to an all-reduce
+    # (expect N(N+1)/2 in every element on every rank) and a broadcast from the last rank must arrive everywhere; the
+    # number of ranks is read back from the transport itself (ncclCommCount).  A job whose ranks silently train alone
+    # fails here instead of printing a perfect-scaling number (VERDICT r2 missing #2).
+    preflight = comm.preflight(native_comm, device, world, rank) if (world > 1 or force) else None
 
     shapes = {"imagenet": (224, 1000, False), "cifar": (32, 10, True), "mnist": (224, 10, False)}
     side, classes, small = shapes[args.shape]
@@ -158,6 +220,7 @@ def worker(args):
         torch.cuda.synchronize()
 
     peak_gb = []
+    run_info = {}
 
     from distributedpytorch_amd.ops.native import set_fp32_mode
 
@@ -195,6 +258,13 @@ def worker(args):
         if world > 1:
             elapsed = comm.all_reduce_scalars([elapsed], "max", device)[0]
         loss, _, _ = dm.epoch_metrics()
+        # after the timed steps every rank must hold bit-identical parameters (a checksum MIN/MAX over the ranks)
+        spread = dm.reducer.check_in_sync()
+        if spread != 0.0:
+            raise RuntimeError(f"ranks diverged during the timed steps: parameter checksum spread {spread}")
+        run_info.update(in_sync_after=True if dm.reducer.active else None,
+                        buckets_mb=[round(b["mbytes"], 2) for b in dm.reducer.describe()],
+                        collectives_issued=native_comm.progress()[0] if native_comm is not None else None)
         peak_gb.append(round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1))
         peak_gb.append(round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 1))
         if dm.arena is not None and dm.arena.plans:
@@ -251,6 +321,13 @@ def worker(args):
                        "image": f"{side}x{side}x3", "classes": classes, "optimizer": args.optimizer,
                        "parallelism": f"dp{world}", "bucket_mb": args.bucket_mb,
                        "comm": native_comm.name if native_comm is not None else "torch",
+                       "comm_ranks": preflight["ranks"] if preflight else None,
+                       "preflight_ok": preflight["ok"] if preflight else None,
+                       "preflight": preflight,
+                       "in_sync_after": run_info.get("in_sync_after"),
+                       "buckets_mb": run_info.get("buckets_mb"),
+                       "collectives_issued": run_info.get("collectives_issued"),
+                       "collective_timeout_s": float(os.environ.get("DPA_COLLECTIVE_TIMEOUT_S", "120")),
                        "fp32_mode": args.fp32_mode if args.dtype == "fp32" else None,
                        "peak_hbm_gb": peak_gb[0] if peak_gb else None,
                        "peak_hbm_reserved_gb": peak_gb[1] if len(peak_gb) > 1 else None,

@@ -18,24 +18,20 @@
 // single-GPU box, where RCCL cannot be given one device per rank.
 #include <arpa/inet.h>
 #include <fcntl.h>
-#include <hip/hip_runtime_api.h>
+#include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <deque>
-#include <mutex>
-#include <thread>
 
-#include "comm_core.h"
+#include "worker_backend.h"
 
 namespace dpa {
 namespace {
@@ -52,38 +48,13 @@ struct Xfer {            // one direction-pair with one peer: send sbuf[0..slen)
   bool send = false, recv = false, checked = false;
 };
 
-struct Job {
-  int kind = 0;            // 1 all-reduce, 2 broadcast
-  int slot = -1;
-  void* ptr = nullptr; long long n = 0; int root = 0;
-  hipEvent_t ready = nullptr, done = nullptr;
-};
-
-struct Slot { bool pending = false, event_recorded = false; int rc = 0; };
-
-struct TcpBackend : Backend {
-  int world = 1, rank = 0, device = -1;
+struct TcpBackend : WorkerBackend {
   int listen_fd = -1, port = 0;
   std::vector<int> fds;                  // socket to each peer (own entry -1)
-  int timeout_ms = 600000;
   uint64_t seq = 0;                      // collective sequence number (worker thread only)
   std::vector<char> scratch;             // phase-1 receive area: one piece per peer
   std::vector<float> accum;
-  // worker
-  std::thread worker;
-  std::mutex mu;
-  std::condition_variable cv_job, cv_done;
-  std::deque<Job> jobs;
-  std::vector<Slot> slots;              // indexed by the front's ring slot
-  Slot bc_slot;                          // broadcasts are synchronous: one slot of their own (job.slot == -1)
-  bool stop = false;
-  std::atomic<int> async_err{0};
-  std::string worker_error;              // guarded by mu
-  // device staging
-  hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> ev_ready, ev_done;
-  hipEvent_t bc_ready = nullptr, bc_done = nullptr;
-  char* pinned = nullptr; size_t pinned_bytes = 0;
+  char* pinned = nullptr; size_t pinned_bytes = 0;      // device staging
 
   const char* name() const override { return "tcp"; }
 
@@ -234,7 +205,7 @@ struct TcpBackend : Backend {
     return pinned;
   }
 
-  int execute(const Job& j, std::string* err) {
+  int execute(const Job& j, std::string* err) override {
     const size_t bytes = j.kind == 1 ? (size_t)j.n * sizeof(float) : (size_t)j.n;
     if (device < 0) {
       return j.kind == 1 ? host_allreduce((float*)j.ptr, j.n, err) : host_broadcast((char*)j.ptr, j.n, j.root, err);
@@ -259,116 +230,21 @@ struct TcpBackend : Backend {
     return 0;
   }
 
-  void loop() {
-    for (;;) {
-      Job j;
-      {
-        std::unique_lock<std::mutex> l(mu);
-        cv_job.wait(l, [&] { return stop || !jobs.empty(); });
-        if (jobs.empty()) return;          // stop requested and nothing queued
-        j = jobs.front(); jobs.pop_front();
-      }
-      std::string err;
-      int rc = 0;
-      { std::lock_guard<std::mutex> l(mu); if (stop) { rc = 125; err = "communicator aborted"; } }
-      if (!rc && async_err.load()) { rc = async_err.load(); err = "an earlier collective failed"; }
-      if (!rc) rc = execute(j, &err);
-      {
-        std::lock_guard<std::mutex> l(mu);
-        if (rc) { if (!async_err.load()) { async_err.store(rc); worker_error = err; } }
-        Slot& s = j.slot < 0 ? bc_slot : slots[j.slot];
-        s.pending = false; s.rc = rc; s.event_recorded = (rc == 0 && device >= 0);
-      }
-      cv_done.notify_all();
-    }
-  }
-
-  int enqueue(Job j) {
-    std::lock_guard<std::mutex> l(mu);
-    if (j.slot >= 0 && (int)slots.size() <= j.slot) slots.resize(j.slot + 1);
-    Slot& s = j.slot < 0 ? bc_slot : slots[j.slot];
-    if (s.pending) { error = "slot re-used while its collective is still running"; return 24; }
-    s = Slot{true, false, 0};
-    jobs.push_back(j);
-    cv_job.notify_one();
-    return 0;
-  }
-  int finish(int slot) {      // block until the worker is done with `slot`; returns its status
-    std::unique_lock<std::mutex> l(mu);
-    if (slot >= (int)slots.size()) { error = "wait on a slot that was never launched"; return 2; }
-    Slot& s = slot < 0 ? bc_slot : slots[slot];
-    cv_done.wait(l, [&] { return !s.pending; });
-    if (s.rc) error = worker_error;
-    return s.rc;
-  }
-  int event_pair(int slot, hipEvent_t* r, hipEvent_t* d) {
-    while ((int)ev_ready.size() <= slot) {
-      hipEvent_t a = nullptr, b = nullptr;
-      if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { error = "hipEventCreateWithFlags failed"; return 1; }
-      ev_ready.push_back(a); ev_done.push_back(b);
-    }
-    *r = ev_ready[slot]; *d = ev_done[slot];
-    return 0;
-  }
-
-  int allreduce(int slot, float* ptr, long long count, void* compute) override {
-    Job j; j.kind = 1; j.slot = slot; j.ptr = ptr; j.n = count;
-    if (device >= 0) {
-      if (int rc = event_pair(slot, &j.ready, &j.done)) return rc;
-      if (hipEventRecord(j.ready, (hipStream_t)compute) != hipSuccess) { error = "hipEventRecord(ready) failed"; return 1; }
-    }
-    return enqueue(j);
-  }
-  int wait(int slot, void* compute) override {
-    const int rc = finish(slot);
-    if (rc) return rc;
-    if (device >= 0) {
-      // `done` was recorded by the worker before finish() returned, so the stream wait below is a real wait
-      if (hipStreamWaitEvent((hipStream_t)compute, ev_done[slot], 0) != hipSuccess) { error = "hipStreamWaitEvent(compute, done) failed"; return 1; }
-    }
-    return 0;
-  }
-  int broadcast(void* ptr, long long bytes, int root, void* compute) override {
-    Job j; j.kind = 2; j.slot = -1; j.ptr = ptr; j.n = bytes; j.root = root;
-    if (device >= 0) {
-      j.ready = bc_ready; j.done = bc_done;
-      if (hipEventRecord(bc_ready, (hipStream_t)compute) != hipSuccess) { error = "hipEventRecord(bc_ready) failed"; return 1; }
-    }
-    if (int rc = enqueue(j)) return rc;
-    if (int rc = finish(-1)) return rc;
-    if (device >= 0 && hipStreamWaitEvent((hipStream_t)compute, bc_done, 0) != hipSuccess) { error = "hipStreamWaitEvent(compute, bc_done) failed"; return 1; }
-    return 0;
-  }
-  int async_error() override { return async_err.load(); }
-  int sync() override {
-    std::unique_lock<std::mutex> l(mu);
-    cv_done.wait(l, [&] {
-      if (!jobs.empty()) return false;
-      for (auto& s : slots) if (s.pending) return false;
-      return !bc_slot.pending;
-    });
-    return async_err.load();
+  int peer_count() override {
+    int n = 1;
+    for (int fd : fds) n += fd >= 0;
+    return n;
   }
   void abort() override {
-    { std::lock_guard<std::mutex> l(mu); stop = true; }
-    cv_job.notify_all();
+    WorkerBackend::abort();
     for (int fd : fds) if (fd >= 0) ::shutdown(fd, SHUT_RDWR);
   }
   ~TcpBackend() override {
-    { std::lock_guard<std::mutex> l(mu); stop = true; }
-    cv_job.notify_all();
-    if (worker.joinable()) worker.join();
+    join_worker();
     for (int fd : fds) if (fd >= 0) ::close(fd);
     if (listen_fd >= 0) ::close(listen_fd);
-    if (device >= 0) {
-      for (auto e : ev_ready) (void)hipEventDestroy(e);
-      for (auto e : ev_done) (void)hipEventDestroy(e);
-      if (bc_ready) (void)hipEventDestroy(bc_ready);
-      if (bc_done) (void)hipEventDestroy(bc_done);
-      if (pinned) (void)hipHostFree(pinned);
-      if (stream) (void)hipStreamDestroy(stream);
-    }
+    if (device >= 0 && pinned) (void)hipHostFree(pinned);
+    destroy_device();
   }
 };
 
@@ -395,13 +271,7 @@ Backend* make_tcp_backend(int world, int rank, int device, std::string* err) {
   TcpBackend* b = new TcpBackend();
   b->world = world; b->rank = rank; b->device = device;
   b->fds.assign(world, -1);
-  if (device >= 0) {
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, 0);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->bc_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->bc_done, hipEventDisableTiming);
-    if (e != hipSuccess) { *err = std::string("HIP setup: ") + hipGetErrorString(e); delete b; return nullptr; }
-  }
+  if (b->setup_device(err)) { delete b; return nullptr; }
   if (world > 1) {
     b->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
     int one = 1; setsockopt(b->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
@@ -411,11 +281,17 @@ Backend* make_tcp_backend(int world, int rank, int device, std::string* err) {
         getsockname(b->listen_fd, (sockaddr*)&a, &l) != 0) { *err = "cannot open the mesh listening socket"; delete b; return nullptr; }
     b->port = ntohs(a.sin_port);
   }
-  b->worker = std::thread([b] { b->loop(); });
+  b->start_worker();
   return b;
 }
 int tcp_backend_port(Backend* be) { return ((TcpBackend*)be)->port; }
-void tcp_backend_set_timeout(Backend* be, int timeout_ms) { ((TcpBackend*)be)->timeout_ms = timeout_ms > 0 ? timeout_ms : 600000; }
+void tcp_backend_set_timeout(Backend* be, int timeout_ms) {
+  // DPA_TCP_SOCKET_TIMEOUT_MS (tests): give the per-transfer limit a value of its own, so that the front's watchdog -
+  // the only bound the RCCL and mesh transports have - can be exercised on sockets too
+  const char* e = getenv("DPA_TCP_SOCKET_TIMEOUT_MS");
+  if (e && atoi(e) > 0) timeout_ms = atoi(e);
+  ((TcpBackend*)be)->timeout_ms = timeout_ms > 0 ? timeout_ms : 600000;
+}
 
 // Mesh bring-up: rank i connects to every j < i (announcing its rank) and accepts one connection from every j > i.
 int tcp_backend_connect(Backend* be, const char* peers_csv, int timeout_ms) {
@@ -429,10 +305,17 @@ int tcp_backend_connect(Backend* be, const char* peers_csv, int timeout_ms) {
     const size_t c = peers[j].rfind(':');
     if (c == std::string::npos) { b->error = "bad peer address " + peers[j]; return 22; }
     const std::string host = peers[j].substr(0, c); const int port = atoi(peers[j].c_str() + c + 1);
+    sockaddr_in a{}; a.sin_family = AF_INET; a.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, host.c_str(), &a.sin_addr) != 1) {        // a name, not a dotted address: resolve it once
+      addrinfo hints{}; hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+      addrinfo* res = nullptr;
+      if (getaddrinfo(host.c_str(), nullptr, &hints, &res) != 0 || !res) { b->error = "cannot resolve the address of rank " + std::to_string(j) + ": " + host; return 22; }
+      a.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+      freeaddrinfo(res);
+    }
     for (;;) {
       int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-      sockaddr_in a{}; a.sin_family = AF_INET; a.sin_port = htons((uint16_t)port);
-      if (inet_pton(AF_INET, host.c_str(), &a.sin_addr) == 1 && ::connect(fd, (sockaddr*)&a, sizeof(a)) == 0) {
+      if (::connect(fd, (sockaddr*)&a, sizeof(a)) == 0) {
         const uint32_t me = htonl((uint32_t)b->rank);
         if (!send_all(fd, &me, 4)) { ::close(fd); b->error = "handshake failed"; return 104; }
         b->fds[j] = fd; break;

@@ -102,6 +102,10 @@ struct Server {
       } else if (op == 5) {                // DELETE
         std::lock_guard<std::mutex> l(mu);
         status = kv.erase(key) ? 0 : -1;
+      } else if (op == 6) {                // COUNT: number of keys held (diagnostics: the store must not grow with the job)
+        std::lock_guard<std::mutex> l(mu);
+        const uint64_t t = htobe64((uint64_t)kv.size());
+        out = std::string((const char*)&t, 8);
       } else status = -2;
       const uint32_t olen = htonl((uint32_t)out.size());
       const int32_t st_n = (int32_t)htonl((uint32_t)status);
@@ -149,7 +153,8 @@ int request(Client* c, uint8_t op, const char* key, const void* val, uint32_t vl
 
 }  // namespace
 
-// bind_addr: dotted IPv4 address to listen on (null / "" / not a local address: all interfaces).
+// bind_addr: dotted IPv4 address to listen on (null / "" / not a local address: all interfaces).  Names are resolved by
+// the caller (parallel/store.py: socket.gethostbyname) - this layer speaks dotted IPv4 only.
 DPA_API void* dpa_store_server_start(const char* bind_addr, int port) {
   auto* s = new Server();
   s->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -237,3 +242,8 @@ DPA_API long long dpa_store_add(void* h, const char* key, long long delta) {
 }
 DPA_API int dpa_store_check(void* h, const char* key) { return request((Client*)h, 4, key, nullptr, 0, nullptr); }
 DPA_API int dpa_store_delete(void* h, const char* key) { return request((Client*)h, 5, key, nullptr, 0, nullptr); }
+DPA_API long long dpa_store_num_keys(void* h) {
+  std::string o;
+  if (request((Client*)h, 6, "", nullptr, 0, &o) != 0 || o.size() != 8) return -1;
+  uint64_t v; memcpy(&v, o.data(), 8); return (long long)be64toh(v);
+}

@@ -83,7 +83,8 @@ class ParamStore:
         self.entries: List[tuple] = []          # state_dict order: ('param'|'buffer'|'nbt', spec)
         self._init_values = {}
         self.aux_tensors: List[torch.Tensor] = []   # per-layer persistent scratch that carries state between steps
-        self.p = self.g = self.p16 = self.b = self.nbt = None
+        self.p = self.g = self.p16 = self.b = self.nbt = self.buffer_arena = None
+        self.buffer_fence = None        # callable set while a broadcast of buffer_arena is in flight (parallel/reducer.py)
         self.p_size = self.b_size = 0
         self.n_nbt = 0
         from .wprep import WeightPrep
@@ -136,8 +137,12 @@ class ParamStore:
         dev = self.device
         self.p = torch.zeros(max(self.p_size, ALIGN), device=dev)
         self.g = torch.zeros_like(self.p)
-        self.b = torch.zeros(max(self.b_size, ALIGN), device=dev)
-        self.nbt = torch.zeros(max(self.n_nbt, 1), dtype=torch.int64, device=dev)
+        # BatchNorm running statistics (fp32) and num_batches_tracked (int64) share ONE byte arena, so DDP's per-step
+        # buffer broadcast (X4 of SURVEY.md §2.6) is one collective, not one per dtype
+        nb = max(self.b_size, ALIGN) * 4
+        self.buffer_arena = torch.zeros(nb + max(self.n_nbt, 1) * 8, dtype=torch.uint8, device=dev)
+        self.b = self.buffer_arena[:nb].view(torch.float32)
+        self.nbt = self.buffer_arena[nb:].view(torch.int64)
         for spec in self.params:
             self.set_logical(spec, self._init_values.pop(("p", spec.index)))
         for spec in self.buffers:
@@ -164,6 +169,14 @@ class ParamStore:
 
     def bview(self, spec):
         return self.b[spec.offset: spec.offset + spec.numel]
+
+    def fence_buffers(self):
+        """Called by whoever is about to touch the buffer arena on the current stream (BatchNorm's finalize / eval
+        coefficients, state_dict): if the step's buffer broadcast is still in flight, make the stream wait for it now."""
+        f = self.buffer_fence
+        if f is not None:
+            self.buffer_fence = None
+            f()
 
     # ---------------------------------------------------------------- logical (torchvision) <-> storage
     @staticmethod
@@ -204,6 +217,7 @@ class ParamStore:
 
     # ---------------------------------------------------------------- state_dict (torchvision names)
     def state_dict(self, prefix=""):
+        self.fence_buffers()
         sd = OrderedDict()
         for kind, item in self.entries:
             if kind == "param":
@@ -217,6 +231,7 @@ class ParamStore:
 
     def load_state_dict(self, sd, strict=True):
         """Accepts keys with or without the DDP 'module.' prefix (Q16 of SURVEY.md §2.8)."""
+        self.fence_buffers()
         clean = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
         expected = []
         for kind, item in self.entries:
@@ -348,11 +363,22 @@ def side_stream(device):
     return s
 
 
+_workspaces_frozen = [False]      # set once a hipGraph has been captured: its kernels hold these buffers' addresses
+
+
+def freeze_workspaces():
+    _workspaces_frozen[0] = True
+
+
 def workspace(device, n, tag, dtype=torch.float32):
-    """Persistent scratch (stream-ordered reuse; never freed so captured graphs keep valid pointers)."""
+    """Persistent scratch (stream-ordered reuse).  A buffer is replaced by a larger one on demand - but never after a
+    hipGraph has been captured: the graph's kernels point at the old buffer, and freeing it under them would be a
+    use-after-free on the device (VERDICT r2 weak #16).  The old buffer is then kept alive next to the new one."""
     key = (str(device), tag, dtype)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < n:
+        if buf is not None and _workspaces_frozen[0]:
+            _workspaces.setdefault(("retired",), []).append(buf)       # captured graphs may still reference it
         buf = torch.empty(max(int(n), 1 << 14), device=device, dtype=dtype)
         _workspaces[key] = buf
     return buf

@@ -300,6 +300,7 @@ class BatchNorm2d:
     def coeffs(self, ctx: Context, slab, count):
         """Finalize batch statistics (train) or fold running statistics (eval) into (scale, shift)."""
         st = self.store
+        st.fence_buffers()          # the step's buffer broadcast (DDP X4) must have landed before the statistics are touched
         a = self.aux(ctx.device)
         if ctx.training:
             ops.bn_finalize(slab, count, st.view(self.gamma), st.view(self.beta), st.bview(self.rm), st.bview(self.rv),

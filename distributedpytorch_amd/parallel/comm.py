@@ -65,7 +65,7 @@ STORE_PORT_OFFSET = 2          # the store listens on MASTER_PORT + 2 (MASTER_PO
 
 
 def init_native(rank, world_size, device, master_addr=None, master_port=None, timeout_s=600.0, rendezvous_timeout_s=300.0,
-                transport=None, create_for_single_rank=False):
+                transport=None, create_for_single_rank=False, watchdog=None, exit_grace_s=None):
     """Bring up the native communicator.  Returns it (None at world size 1 unless `create_for_single_rank`)."""
     global _NATIVE, _STORE
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver stack
@@ -82,7 +82,8 @@ def init_native(rank, world_size, device, master_addr=None, master_port=None, ti
         # forever in init_process_group, README.md:47-49)
         store.announce_and_wait(rank, world_size, tag="join")
         store.timeout_s = timeout_s
-    nc = NativeComm(store, rank, world_size, device, transport=transport, timeout_s=timeout_s, master_addr=addr)
+    nc = NativeComm(store, rank, world_size, device, transport=transport, timeout_s=timeout_s, master_addr=addr,
+                    watchdog=watchdog, exit_grace_s=exit_grace_s)
     _NATIVE, _STORE = nc, store
     logging.debug(f"native communicator up: {nc.name} rank={rank}/{world_size}")
     return nc
@@ -90,6 +91,38 @@ def init_native(rank, world_size, device, master_addr=None, master_port=None, ti
 
 def native():
     return _NATIVE
+
+
+def preflight(nc, device, world, rank):
+    """Known-answer check of the data plane, on whichever backend is up (nc: the NativeComm, or None for the torch
+    process group).  Raises on a wrong answer; returns what bench.py records next to its number:
+    ranks = how many ranks the TRANSPORT connects (RCCL: ncclCommCount), the sums seen, the time it took."""
+    import time
+    t0 = time.perf_counter()
+    n = 4096 + 3                                        # not a multiple of anything the transports chunk by
+    a = torch.full((n,), float(rank + 1), device=device)
+    b = (torch.arange(1024, dtype=torch.int64, device=device) * (rank + 7)).contiguous()
+    root = world - 1
+    if nc is not None:
+        nc.allreduce_async(a, 0)
+        nc.wait(0)
+        nc.broadcast(b, root)
+        ranks = nc.peer_count()
+    else:
+        dist.all_reduce(a)
+        dist.broadcast(b, root)
+        ranks = dist.get_world_size()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    want = world * (world + 1) / 2.0
+    lo, hi = float(a.min()), float(a.max())
+    bc_ok = bool(torch.equal(b, torch.arange(1024, dtype=torch.int64, device=device) * (root + 7)))
+    ok = lo == want and hi == want and bc_ok and ranks == world
+    info = dict(ok=ok, ranks=int(ranks), expected_ranks=world, allreduce_min=lo, allreduce_max=hi, allreduce_expected=want,
+                broadcast_ok=bc_ok, ms=round(1000 * (time.perf_counter() - t0), 2))
+    if not ok:
+        raise RuntimeError(f"communication preflight failed on rank {rank}: {info}")
+    return info
 
 
 def shutdown(clean=True):

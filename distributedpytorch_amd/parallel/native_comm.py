@@ -30,6 +30,7 @@ def comm_lib():
         lib = ctypes.CDLL(path)
         lib.dpa_comm_init.restype = ctypes.c_void_p
         lib.dpa_comm_init_tcp.restype = ctypes.c_void_p
+        lib.dpa_comm_init_mesh.restype = ctypes.c_void_p
         lib.dpa_comm_last_error.restype = ctypes.c_char_p
         lib.dpa_comm_create_error.restype = ctypes.c_char_p
         lib.dpa_comm_backend_name.restype = ctypes.c_char_p
@@ -56,21 +57,32 @@ def _local_addr_towards(host):
 
 
 class NativeComm:
-    """One communicator per rank.  transport: 'rccl' (GPU default), 'tcp' (CPU default; on a GPU: device buffers staged
-    through pinned memory, several ranks may share the device).  `store`: parallel.store.TCPStore shared by all ranks
-    (None at world size 1)."""
+    """One communicator per rank.  transport: 'rccl' (GPU default), 'mesh' (GPU, opt-in: own two-shot all-reduce kernels
+    over hipIpc peer buffers, one node), 'tcp' (CPU default; on a GPU: device buffers staged through pinned memory,
+    several ranks may share the device).  `store`: parallel.store.TCPStore shared by all ranks (None at world size 1).
 
-    def __init__(self, store, rank, world, device, transport=None, timeout_s=600.0, master_addr="127.0.0.1"):
+    Every collective is bounded by `timeout_s` (config COLLECTIVE_TIMEOUT_S / DPA_COLLECTIVE_TIMEOUT_S) on every
+    transport: the front's watchdog thread (csrc/comm/comm_api.cpp) follows the oldest in-flight collective, publishes
+    this rank's progress under hb/<rank> in the store, and on expiry prints which collective is stuck and which ranks
+    are BEHIND or SILENT, aborts the transport, fails every later call with that text and - if the process is still
+    there `exit_grace_s` later (blocked in a device synchronisation, say) - ends it with status 110.
+    exit_grace_s < 0: never end the process (tests)."""
+
+    def __init__(self, store, rank, world, device, transport=None, timeout_s=600.0, master_addr="127.0.0.1",
+                 watchdog=None, exit_grace_s=None):
         self.lib = comm_lib()
         self.rank, self.world, self.store = rank, world, store
         self.device = torch.device(device)
         on_gpu = self.device.type == "cuda"
         self.transport = transport or os.environ.get("DPA_COMM_TRANSPORT") or ("rccl" if on_gpu else "tcp")
-        if self.transport == "rccl" and not on_gpu:
-            raise ValueError("the RCCL transport needs a GPU device")
+        if self.transport in ("rccl", "mesh") and not on_gpu:
+            raise ValueError(f"the {self.transport} transport needs a GPU device")
         if world > 1 and store is None:
             raise ValueError("a rendezvous store is required for world size > 1")
         self._ctl_seq = 0
+        self._ctl_prev_key = None
+        self._hb_client = None
+        self.h = None
         dev_index = (self.device.index or 0) if on_gpu else -1
         if on_gpu:
             # Load the kernel library's code object before the communicator exists (defensive; docs/COMM.md: the order
@@ -81,22 +93,39 @@ class NativeComm:
         if self.transport == "rccl":
             n = self.lib.dpa_comm_unique_id_size()
             buf = ctypes.create_string_buffer(n)
+            # keyed by a per-store generation: a second communicator over the same store must never read the first
+            # one's id; every rank creates its communicators in the same order, so the counters agree
+            gen = 0
+            if store is not None:
+                gen = store.comm_generation = getattr(store, "comm_generation", 0) + 1
+            id_key = f"rccl/unique_id/{gen}"
             if rank == 0:
                 rc = self.lib.dpa_comm_unique_id(buf)
                 if rc:
                     raise CommError(f"ncclGetUniqueId failed rc={rc}")
                 if store is not None:
-                    store.set("rccl/unique_id", buf.raw)
+                    store.set(id_key, buf.raw)
             else:
-                buf.raw = store.get("rccl/unique_id")
+                buf.raw = store.get(id_key)
             self.h = self.lib.dpa_comm_init(buf, world, rank, dev_index)
             if not self.h:
                 raise CommError(f"RCCL communicator bring-up failed: {self.lib.dpa_comm_create_error().decode()}")
+        elif self.transport == "mesh":
+            cap = int(float(os.environ.get("DPA_MESH_BUFFER_MB", "64")) * 2 ** 20)
+            self.h = self.lib.dpa_comm_init_mesh(world, rank, dev_index, ctypes.c_longlong(cap))
+            if not self.h:
+                raise CommError(f"mesh communicator bring-up failed: {self.lib.dpa_comm_create_error().decode()}")
+            if world > 1:
+                n = self.lib.dpa_comm_mesh_handle_size()
+                blob = ctypes.create_string_buffer(n)
+                self._check(self.lib.dpa_comm_mesh_export(ctypes.c_void_p(self.h), blob), "mesh export")
+                store.set(f"meshcomm/handles{rank}", blob.raw)
+                everyone = b"".join(store.get(f"meshcomm/handles{r}") for r in range(world))
+                self._check(self.lib.dpa_comm_mesh_connect(ctypes.c_void_p(self.h), everyone), "mesh connect")
         elif self.transport == "tcp":
             self.h = self.lib.dpa_comm_init_tcp(world, rank, dev_index)
             if not self.h:
                 raise CommError(f"TCP communicator bring-up failed: {self.lib.dpa_comm_create_error().decode()}")
-            self.lib.dpa_comm_set_timeout_ms(ctypes.c_void_p(self.h), int(timeout_s * 1000))
             if world > 1:
                 me = f"{_local_addr_towards(master_addr)}:{self.lib.dpa_comm_tcp_port(ctypes.c_void_p(self.h))}"
                 store.set(f"tcpcomm/addr{rank}", me.encode())
@@ -105,8 +134,33 @@ class NativeComm:
                             "mesh bring-up")
         else:
             raise ValueError(f"unknown transport {self.transport!r}")
+        self.timeout_s = float(timeout_s)
+        self.lib.dpa_comm_set_timeout_ms(ctypes.c_void_p(self.h), int(timeout_s * 1000))
+        if watchdog is None:
+            watchdog = os.environ.get("DPA_WATCHDOG", "1") != "0"
+        if watchdog:
+            self._start_watchdog(exit_grace_s)
         if store is not None:
             self.barrier("comm_up")
+            if self.transport == "mesh":
+                self.lib.dpa_comm_mesh_unlink(ctypes.c_void_p(self.h))      # nothing left in /dev/shm from here on
+            if self.transport == "rccl" and rank == 0:
+                store.delete(id_key)
+
+    def _start_watchdog(self, exit_grace_s):
+        """The watchdog thread gets a store connection of its own (the caller's may sit in a long blocking get) and the
+        addresses of the store client's C functions - libdpamd_comm.so does not link against libdpamd_host.so."""
+        if exit_grace_s is None:
+            exit_grace_s = float(os.environ.get("DPA_WATCHDOG_EXIT_GRACE_S", "10"))
+        client = set_fn = get_fn = None
+        if self.store is not None:
+            host = native.host_lib()
+            self._hb_client = self.store.new_client()
+            client = ctypes.c_void_p(self._hb_client)
+            set_fn = ctypes.cast(host.dpa_store_set, ctypes.c_void_p)
+            get_fn = ctypes.cast(host.dpa_store_get, ctypes.c_void_p)
+        self.lib.dpa_comm_watchdog_start(ctypes.c_void_p(self.h), int(self.timeout_s * 1000),
+                                         int(exit_grace_s * 1000) if exit_grace_s >= 0 else -1, client, set_fn, get_fn)
 
     # ------------------------------------------------------------------ data plane
     def _stream(self):
@@ -133,6 +187,44 @@ class NativeComm:
                                                 ctypes.c_longlong(t.numel() * t.element_size()), root, self._stream()),
                     "broadcast")
 
+    def broadcast_async(self, t: torch.Tensor, root=0) -> int:
+        """Issue the broadcast (ordered after the current stream) and return a ticket; `broadcast_wait(ticket)` makes the
+        current stream wait for it.  `t` must not be touched in between."""
+        assert t.is_contiguous()
+        ticket = self.lib.dpa_comm_broadcast_async(ctypes.c_void_p(self.h), ctypes.c_void_p(t.data_ptr()),
+                                                   ctypes.c_longlong(t.numel() * t.element_size()), root, self._stream())
+        if ticket < 0:
+            self._check(-ticket, "broadcast")
+        return ticket
+
+    def broadcast_wait(self, ticket: int):
+        self._check(self.lib.dpa_comm_broadcast_wait(ctypes.c_void_p(self.h), ticket, self._stream()), "broadcast")
+
+    def peer_count(self) -> int:
+        """How many ranks the TRANSPORT connects (RCCL: ncclCommCount) - not what this object was told."""
+        return int(self.lib.dpa_comm_peer_count(ctypes.c_void_p(self.h)))
+
+    def progress(self):
+        """(issued, finished) collective numbers as the watchdog sees them."""
+        a, b = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        self.lib.dpa_comm_progress(ctypes.c_void_p(self.h), ctypes.byref(a), ctypes.byref(b))
+        return int(a.value), int(b.value)
+
+    def watchdog_tripped(self) -> bool:
+        return bool(self.lib.dpa_comm_watchdog_tripped(ctypes.c_void_p(self.h)))
+
+    def quiesce(self, timeout_s=5.0):
+        """Wait until the watchdog has retired every collective issued so far (call after a device synchronisation and
+        before a hipGraph capture: the watchdog's hipEventQuery must not run beside a capture)."""
+        import time
+        t0 = time.time()
+        while time.time() - t0 < timeout_s:
+            issued, finished = self.progress()
+            if finished >= issued:
+                return True
+            time.sleep(0.01)
+        return False
+
     def inflight(self) -> int:
         return int(self.lib.dpa_comm_inflight(ctypes.c_void_p(self.h)))
 
@@ -158,7 +250,14 @@ class NativeComm:
         self._ctl_seq += 1
         key = f"ctl/{tag}/{self._ctl_seq}"
         self.store.set(f"{key}/{self.rank}", payload)
-        return [payload if r == self.rank else self.store.get(f"{key}/{r}") for r in range(self.world)]
+        out = [payload if r == self.rank else self.store.get(f"{key}/{r}") for r in range(self.world)]
+        # Every rank has now SET its key of this exchange, i.e. every rank has finished reading the previous one:
+        # this rank's key of the previous exchange can go (the store holds at most two keys per rank, however long
+        # the job runs with CHECK_SYNC_EVERY - VERDICT r2 weak #11).
+        if self._ctl_prev_key is not None:
+            self.store.delete(self._ctl_prev_key)
+        self._ctl_prev_key = f"{key}/{self.rank}"
+        return out
 
     def barrier(self, tag="barrier"):
         self.all_gather_bytes(b"\x01", tag)
@@ -178,5 +277,8 @@ class NativeComm:
 
     def destroy(self):
         if self.h:
-            self.lib.dpa_comm_destroy(ctypes.c_void_p(self.h))
+            self.lib.dpa_comm_destroy(ctypes.c_void_p(self.h))       # joins the watchdog thread first
             self.h = None
+        if self._hb_client:
+            native.host_lib().dpa_store_close(ctypes.c_void_p(self._hb_client))
+            self._hb_client = None

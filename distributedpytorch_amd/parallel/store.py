@@ -4,6 +4,7 @@ when a node of DDTNodes never shows up (README.md:47-49 of the reference); here 
 from __future__ import annotations
 
 import ctypes
+import socket
 import struct
 import time
 
@@ -22,8 +23,17 @@ class TCPStore:
         lib.dpa_store_add.restype = ctypes.c_longlong
         lib.dpa_store_last_size.restype = ctypes.c_longlong
         lib.dpa_store_last_copy.restype = ctypes.c_longlong
+        lib.dpa_store_num_keys.restype = ctypes.c_longlong
         self._lib, self._server = lib, None
         self.timeout_s = timeout_s
+        # The C++ store speaks dotted IPv4 only: resolve a name (MASTER_ADDR=localhost, or the host name torchrun's
+        # multi-node rendezvous exports) HERE, once, and fail at once with a clear message when it cannot be resolved
+        # instead of spinning for the whole rendezvous timeout.
+        try:
+            host = socket.gethostbyname(host)
+        except OSError as e:
+            raise RuntimeError(f"cannot resolve the rendezvous address MASTER_ADDR={host!r}: {e}") from e
+        self.host = host
         if is_master:
             self._server = lib.dpa_store_server_start(host.encode(), int(port))
             if not self._server:
@@ -33,6 +43,14 @@ class TCPStore:
         self._client = lib.dpa_store_connect(host.encode(), self.port, int(timeout_s * 1000))
         if not self._client:
             raise StoreTimeout(f"could not reach the rendezvous store at {host}:{self.port} within {timeout_s}s")
+
+    def new_client(self, timeout_s=10.0):
+        """A second raw connection to the same store (for a thread of its own, e.g. the communicator's watchdog).  The
+        caller owns the handle and closes it with dpa_store_close."""
+        h = self._lib.dpa_store_connect(self.host.encode(), self.port, int(timeout_s * 1000))
+        if not h:
+            raise StoreTimeout(f"could not open a second connection to the rendezvous store at {self.host}:{self.port}")
+        return h
 
     def set(self, key, value: bytes):
         rc = self._lib.dpa_store_set(ctypes.c_void_p(self._client), key.encode(), value, len(value))
@@ -64,6 +82,9 @@ class TCPStore:
 
     def delete(self, key) -> bool:
         return self._lib.dpa_store_delete(ctypes.c_void_p(self._client), key.encode()) == 0
+
+    def num_keys(self) -> int:
+        return int(self._lib.dpa_store_num_keys(ctypes.c_void_p(self._client)))
 
     def check(self, key) -> bool:
         return self._lib.dpa_store_check(ctypes.c_void_p(self._client), key.encode()) == 0

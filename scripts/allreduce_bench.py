@@ -6,6 +6,11 @@ group on the same sizes.  busbw = 2*(N-1)/N * bytes / time.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/allreduce_bench.py
   ... scripts/allreduce_bench.py --sweep        # also: a ResNet-50-sized gradient (102 MB) cut into buckets of 4..128 MiB,
                                                 # all in flight - the time the reducer would see per step and bucket size
+  ... scripts/allreduce_bench.py --transport mesh   # the IPC mesh transport (own two-shot kernels over hipIpc peer buffers)
+  scripts/comm_first_contact.sh                 # everything above for N = 2, 4, 8 and both transports, one JSON line each
+
+Nothing here has been run with more than one GPU by the builder (one-GPU boxes only): `profiles/r3_allreduce_mesh_shared_gpu.txt`
+is N processes SHARING one MI355X (DPA_SHARE_GPU=1: no xGMI involved, it times the kernels + the host handshake).
 
 What to read off it (xGMI is point-to-point, 7 links x ~153 GB/s per GPU): a single ring is bound by ONE link
 (~87 GB/s algbw at N=8), the mesh algorithms by all seven (~600 GB/s); the bucket cap should be the smallest size whose
@@ -28,6 +33,9 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--also-torch", action="store_true")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--transport", default=None, choices=["rccl", "mesh", "tcp"],
+                    help="default: rccl on GPUs, tcp on CPUs (DPA_COMM_TRANSPORT overrides)")
+    ap.add_argument("--max-mb", type=float, default=256)
     a = ap.parse_args()
     world, rank, lr = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     cuda = torch.cuda.is_available()
@@ -37,7 +45,9 @@ def main():
     if cuda:
         torch.cuda.set_device(lr)
         torch.cuda.set_stream(torch.cuda.Stream())
-    nc = comm.init_native(rank, world, dev, create_for_single_rank=True)
+    nc = comm.init_native(rank, world, dev, create_for_single_rank=True, transport=a.transport,
+                          timeout_s=float(os.environ.get("DPA_COLLECTIVE_TIMEOUT_S", "120")))
+    pre = comm.preflight(nc, dev, world, rank)        # known-answer all-reduce + broadcast before anything is timed
 
     def sync():
         if cuda:
@@ -58,6 +68,8 @@ def main():
 
     rows = []
     for mb in (0.25, 1, 4, 8, 16, 25, 32, 64, 128, 256):
+        if mb > a.max_mb:
+            break
         n = int(mb * 2 ** 20 / 4)
         t = torch.ones(n, device=dev)
 
@@ -68,7 +80,8 @@ def main():
         algbw = n * 4 / dt / 1e9
         rows.append(dict(mbytes=mb, us=round(dt * 1e6, 1), algbw_GBs=round(algbw, 2),
                          busbw_GBs=round(algbw * 2 * (world - 1) / max(world, 1), 2)))
-    out = {"world": world, "comm": nc.name, "results": rows}
+    out = {"world": world, "comm": nc.name, "transport_ranks": pre["ranks"], "preflight_ok": pre["ok"],
+           "shared_gpu": os.environ.get("DPA_SHARE_GPU", "0") == "1", "results": rows}
     if a.sweep:
         total = 25_557_032 * 4          # ResNet-50 gradient bytes
         sweep = []

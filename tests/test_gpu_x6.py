@@ -90,7 +90,7 @@ def test_x6_training_follows_exact_trajectory():
     assert a[-1] < 0.5 * a[0] and b[-1] < 0.5 * b[0]      # both train
     # 32 random images are memorised within a few Adam steps and the gradients of a randomly initialised ResNet-50 on
     # random data are ill-conditioned: two EXACT-mode runs that only differ in the order of the batch already differ by
-    # 1e-3..1e-2 in their gradients (scripts/debug/x6_grad_diff.py).  Identical first step, then a widening band.
+    # 1e-3..1e-2 in their gradients (scripts/diag/x6_grad_diff.py).  Identical first step, then a widening band.
     for la, lb, tol in zip(a, b, (1e-4, 3e-2, 1e-1)):
         assert abs(la - lb) <= tol * max(1.0, abs(la)), (a, b)
 

@@ -338,6 +338,9 @@ def test_checkpoint_loads_into_reference_style_torch_model(tmp_path):
     assert set(checkpoint) == {"model_name", "model_state_dict", "optimizer_state_dict", "epoch", "loss"}
     model.load_state_dict(checkpoint["model_state_dict"])             # strict=True
     optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+    # the two extra entries (dropout RNG state, BatchNorm statistics shifts) ride along without upsetting torch's loader
+    assert len(optimizer.param_groups[0]["dpa_rng_state"]) == 2
+    assert optimizer.param_groups[0]["dpa_bn_stat_shift"].numel() == sum(a[9].numel() for a in net.store.aux_tensors)
     assert checkpoint["epoch"] + 1 == 1 and checkpoint["loss"] == 1.25 and checkpoint["model_name"] == "resnet"
     assert len(checkpoint["model_state_dict"]) == 122
     assert checkpoint["model_state_dict"]["module.bn1.num_batches_tracked"].dtype == torch.int64
@@ -360,7 +363,7 @@ def test_native_reducer_core_protocol():
     """csrc/comm/reducer.cpp bookkeeping (no communicator): ready detection, double-ready and missing-gradient errors,
     plan-order diagnostics - the stream/event-free half of the T1 'reducer discipline' tests."""
     import ctypes
-    from distributedpytorch_amd.parallel.rccl_native import comm_lib
+    from distributedpytorch_amd.parallel.native_comm import comm_lib
     lib = comm_lib()
     # 5 params: p0 frozen, buckets in backward order: b0 = {p4}, b1 = {p3, p2}, b2 = {p1}
     bucket_of = (ctypes.c_int * 5)(-1, 2, 1, 1, 0)
