@@ -66,7 +66,14 @@ def _check_kernel_stubs(so):
                            + ", ".join(missing[:4]))
 
 
-def build(force=False, jobs=None, verbose=True):
+def build(force=False, jobs=None, verbose=True, libdir=None, defines=()):
+    """libdir / defines: an A/B build of the kernels with extra -D flags into another directory (selected at run time with
+    DPA_LIB_DIR); the default build is what ships."""
+    global LIBDIR, OBJDIR
+    if libdir:
+        LIBDIR = os.path.abspath(libdir)
+        OBJDIR = os.path.join(LIBDIR, "obj")
+    extra = [f"-D{d}" for d in defines]
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     jobs = jobs or min(8, os.cpu_count() or 4)
@@ -86,7 +93,7 @@ def build(force=False, jobs=None, verbose=True):
             objs[kind].append(obj)
             if kind == "hip":
                 fm = ["-ffast-math"] if os.path.basename(src) in FAST_MATH_TUS else []
-                cmd = [HIPCC] + HIP_FLAGS + fm + ["-c", src, "-o", obj]
+                cmd = [HIPCC] + HIP_FLAGS + fm + extra + ["-c", src, "-o", obj]
             elif kind == "comm" and src.endswith(".hip"):      # the mesh transport: host runtime + its reduce kernels
                 cmd = [HIPCC] + HIP_FLAGS + [f"-I{ROCM}/include", "-pthread", "-c", src, "-o", obj]
             elif kind == "comm":
@@ -136,5 +143,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--libdir", default=None, help="A/B build into this directory (run with DPA_LIB_DIR=<dir>)")
+    ap.add_argument("-D", dest="defines", action="append", default=[], help="extra preprocessor define for the kernel TUs")
     a = ap.parse_args()
-    build(force=a.force, jobs=a.jobs)
+    build(force=a.force, jobs=a.jobs, libdir=a.libdir, defines=a.defines)

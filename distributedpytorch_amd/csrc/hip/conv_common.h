@@ -54,16 +54,6 @@ struct ConvParams {
   int bnr_cs, bnr_y_cs;
   int bnr_row0;              // first slab row of this parity class (host)
   int bnr_pad;
-  // EXPERIMENT (scripts/bench_norm_on_load.py, docs/KERNELS.md §4): fprop applies relu(src * nol_scale[c] + nol_shift[c])
-  // to the activation fragments before the split ("normalise-on-load").  Padding pixels are NOT handled (they would
-  // have to stay zero after the transform), so only 1x1 / unpadded problems are numerically meaningful; the 3x3
-  // timing is representative.  Not used by the framework.
-  const float* nol_scale;
-  const float* nol_shift;
-  // EXPERIMENT (scripts/bench_x6pp.py, docs/KERNELS.md §2): the ACTIVATION operand pre-split into three bf16 planes as well
-  // ("producer-side split"): [3][sN*sH*sW*s_cs] bf16.  The x6p kernel then has no VALU split at all.  Not used by the framework.
-  const void* src3;
-  long long src3_plane;
   // Per-output-channel multiplier applied to the accumulator BEFORE the bias: out = acc * oscale[c] + bias[c] (+ addend)
   // (ReLU).  With oscale = gamma / sqrt(running_var + eps) and bias = beta - running_mean * oscale this is an inference
   // BatchNorm folded into the convolution (fprop only; null = 1).
@@ -119,7 +109,22 @@ template <> struct MfmaT<float> {
 // roundings: 32 products per instruction instead of 4) - scripts/x6_accuracy.py, profiles/README.md.
 // The bf16 pipe does 16x the MACs per cycle of the fp32 one, so 6 products still cost 2.7x fewer matrix cycles.
 extern "C" int dpa_get_fp32_mode();      // 0 = exact fp32 MFMA, 1 = x6 (default); DPA_FP32_MODE / dpa_set_fp32_mode
-__device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) {
+// Two ways to cut x into three bf16 parts, both EXACT (8 + 8 + 8 significant bits):
+//   round-to-nearest (default): p = bf16_rn(r), r -= p.  v_cvt_pk_bf16_f32 + v_pk_add_f32 per part;
+//   truncation (-DDPA_SPLIT_TRUNC=1, an A/B build: csrc/build.py --libdir ... -D DPA_SPLIT_TRUNC=1): p = r & 0xffff0000
+//     (the top 16 bits of an fp32 ARE a bf16), r -= p.  v_and_b32 + v_sub_f32 + one v_perm_b32 per pair - 11 instructions
+//     per pair instead of 9, but none of the two kinds that profiles/r1_micro_valu_mfma_coissue.txt showed not overlapping
+//     with MFMAs.  MEASURED in round 3 over the ResNet-50 layer table at batch 1024 (profiles/r3_split_trunc_ab.txt):
+//     fprop 51.6 vs 52.3 ms, dgrad 66.7 vs 68.0, wgrad 52.9 vs 51.6 - 171.2 vs 171.8 ms in total, i.e. nothing: the
+//     split's instruction kinds are not what holds the x6 kernels at 57-64 % matrix-pipe utilisation.  Truncated parts all
+//     carry the sign of x, so the dropped cross terms become one-signed; with no speed to buy, the default stays RN.
+#ifndef DPA_SPLIT_TRUNC
+#define DPA_SPLIT_TRUNC 0
+#endif
+// round-to-nearest parts: the once-per-step filter planes (weight_prep_kernel) always use these - they are not in any K
+// loop, and with zero-mean filter remainders the cross terms dropped against truncated ACTIVATION parts are zero-mean too
+// (fprop / dgrad keep no one-signed bias at all; only wgrad, where both operands are split in the loop, has one)
+__device__ __forceinline__ void split3_pair_rn(float x, float y, uint32_t (&o)[3]) {
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   f32x2_t r = {x, y};
@@ -132,6 +137,23 @@ __device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) 
       r.y -= __uint_as_float(h & 0xffff0000u);
     }
   }
+}
+__device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) {
+#if DPA_SPLIT_TRUNC
+  uint32_t ux = __float_as_uint(x), uy = __float_as_uint(y);
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    o[part] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);      // (uy & 0xffff0000) | (ux >> 16)
+    if (part < 2) {
+      float rx, ry;      // (asm: two v_sub_f32, not one v_pk_add_f32 - the packed form is what does not overlap with MFMAs)
+      asm("v_sub_f32 %0, %1, %2" : "=v"(rx) : "v"(__uint_as_float(ux)), "v"(__uint_as_float(ux & 0xffff0000u)));
+      asm("v_sub_f32 %0, %1, %2" : "=v"(ry) : "v"(__uint_as_float(uy)), "v"(__uint_as_float(uy & 0xffff0000u)));
+      ux = __float_as_uint(rx); uy = __float_as_uint(ry);
+    }
+  }
+#else
+  split3_pair_rn(x, y, o);
+#endif
 }
 // order of the six partial products: small terms first
 __device__ constexpr int kX6A[6] = {1, 2, 0, 1, 0, 0};

@@ -44,6 +44,15 @@ __device__ __forceinline__ void split3_frag(const uint4& lo, const uint4& hi, ui
   for (int part = 0; part < 3; ++part) pl[part] = make_uint4(o[0][part], o[1][part], o[2][part], o[3][part]);
 }
 
+__device__ __forceinline__ void split3_frag_rn(const uint4& lo, const uint4& hi, uint4 (&pl)[3]) {      // filter planes
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t o[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split3_pair_rn(__uint_as_float(w[2 * q]), __uint_as_float(w[2 * q + 1]), o[q]);
+#pragma unroll
+  for (int part = 0; part < 3; ++part) pl[part] = make_uint4(o[0][part], o[1][part], o[2][part], o[3][part]);
+}
+
 // n fp32 values (n % 32 == 0) -> three bf16 planes of n values each.  One thread per 8 values.
 __global__ void __launch_bounds__(256) split3_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long long n) {
   const long long nchunks = n >> 3;
@@ -51,8 +60,8 @@ __global__ void __launch_bounds__(256) split3_planes_kernel(const float* __restr
     const float4 lo = *reinterpret_cast<const float4*>(w + c * 8);
     const float4 hi = *reinterpret_cast<const float4*>(w + c * 8 + 4);
     uint4 pl[3];
-    split3_frag(make_uint4(__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)),
-                make_uint4(__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)), pl);
+    split3_frag_rn(make_uint4(__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)),
+                   make_uint4(__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)), pl);
 #pragma unroll
     for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(out + (long long)part * n + c * 8) = pl[part];
   }
@@ -146,8 +155,8 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const WPrepSeg* __rest
   if constexpr (sizeof(T) == 4) {
     if (sg.planes) {
       uint4 pl[3];
-      split3_frag(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])),
-                  make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])), pl);
+      split3_frag_rn(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])),
+                     make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])), pl);
       bf16_t* out = reinterpret_cast<bf16_t*>(sg.planes);
 #pragma unroll
       for (int part = 0; part < 3; ++part) *reinterpret_cast<uint4*>(out + (long long)part * sg.n + i0) = pl[part];
@@ -164,21 +173,17 @@ DPA_API int dpa_weight_prep(const void* segs, int nsegs, long long total_chunks,
 }
 DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
 
-// NW waves per block, stacked along M: NW = 4 -> 128 x BN tile, two blocks per CU; NW = 8 -> 256 x BN tile, one block of
-// 512 threads per CU (the filter planes are staged once for twice the rows, and both waves of a SIMD share one barrier).
-// TMW row tiles (16 rows each) per wave: 2 -> 128-row block tile, two blocks per CU.  4 -> 256-row block tile, ONE block per
-// CU (112 KB of LDS, one wave per SIMD with up to 512 registers): every filter fragment a wave reads from LDS feeds four
-// row tiles instead of two, so LDS reads per MFMA drop by 43 % and LDS-DMA bytes per MFMA by 30 %.  EXPERIMENT, not the
-// default: it is 10-15 % slower on every ResNet-50 layer (3x3 steady state 208 -> 178 TFLOP/s) - LDS bytes are not what
-// holds the 128-row tile at 64 % MFMA utilisation; with one wave per SIMD nothing covers a wave's own LDS / barrier waits
-// and operand splits, which the second resident block of the 128-row configuration does.
-template <int TN, bool DGRAD, int NW, int MF, bool NOL = false, bool APL = false, int TMW = 2>
-__global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(const ConvParams p) {
-  static_assert(TMW == 2 || (TMW == 4 && !NOL && !APL), "experiment instantiations exist for the 128-row tile only");
+// NW = 4 waves per block, stacked along M; each wave owns TMW = 2 row tiles of 16 rows: a 128 x BN block tile, two blocks
+// per CU.  Variants that were measured and lost in round 2 are NOT compiled into the library any more (VERDICT r2 weak
+// #10); their code is in the history (commit 6a4c0f5) and their numbers in profiles/: 8 waves / 256-row tiles, one block
+// per CU with 4 row tiles per wave ("tall": 10-15 % slower, r2_x6p_tall_tile.txt), activations pre-split into planes by
+// the producer ("x6pp": 23-30 % slower, r2_x6pp_activation_planes.txt), normalise-on-load (< 1 % net, r2_norm_on_load.txt).
+template <int TN, bool DGRAD, int NW, int MF>
+__global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p) {
+  constexpr int TMW = 2;
   constexpr int WROWS = 16 * TMW;                  // rows of the block tile a wave owns
   constexpr int BM = WROWS * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
-  constexpr int AP_BYTES = BM * 64;                // one plane of the activation tile (APL: experiment, see ConvParams::src3)
-  constexpr int A_BYTES = APL ? 3 * AP_BYTES : BM * 128, BP_BYTES = BN * 64;
+  constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
   constexpr int STAGE_BYTES = A_BYTES + 3 * BP_BYTES;
   constexpr int RPP = NT / 8;                      // rows staged per pass (8 threads per 128-byte row)
   constexpr int A_PASSES = BM / RPP;               // = 4
@@ -227,40 +232,6 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
       a_mask[i] = mk;
     }
   }
-  // ---- APL: the activation tile as three planes, staged in 1-KiB pieces exactly like the filter planes -----------------
-  constexpr int AP_PIECES = APL ? (3 * (BM / 16)) / NW : 1;
-  long long ap_off[AP_PIECES];
-  uint32_t ap_mask[AP_PIECES];
-  int ap_lds[AP_PIECES];
-  if constexpr (APL) {
-#pragma unroll
-    for (int i = 0; i < AP_PIECES; ++i) {
-      const int q = wave + NW * i;
-      const int plane = q / (BM / 16), r16 = q - plane * (BM / 16);
-      const int row = 16 * r16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ ((-(row >> 2)) & 3);
-      const int m = m0 + row;
-      ap_mask[i] = 0; ap_off[i] = 0;
-      ap_lds[i] = plane * AP_BYTES + r16 * 1024;
-      if (m < p.M) {
-        const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
-        const int xo = m - (int)t1 * p.cls_nw;
-        const uint32_t img = fd_div(t1, p.fd_nH);
-        const int yo = (int)t1 - (int)img * p.cls_nh;
-        const int y0 = DGRAD ? yo + p.base_y : yo * p.sh - p.ph;
-        const int x0 = DGRAD ? xo + p.base_x : xo * p.sw - p.pw;
-        ap_off[i] = (long long)plane * p.src3_plane + ((long long)img * (p.sH * p.sW) + (long long)y0 * p.sW + x0) * p.s_cs + p.s_co + chunk * 8;
-        uint32_t mk = 0;
-        for (int t = 0; t < ntaps; ++t) {
-          const int r = (int)fd_div((uint32_t)t, p.fd_nS), s_ = t - r * p.nS;
-          const int sy = DGRAD ? y0 - r : y0 + r;
-          const int sx = DGRAD ? x0 - s_ : x0 + s_;
-          if (((unsigned)sy < (unsigned)p.sH) && ((unsigned)sx < (unsigned)p.sW)) mk |= 1u << t;
-        }
-        ap_mask[i] = mk;
-      }
-    }
-  }
   // ---- B operand: piece q = wave + NW i of the K-tile: plane q / TN, rows 16 (q % TN) .. + 15; lane -> row lane >> 2,
   //      slot lane & 3, which holds logical chunk slot ^ ((-(row >> 2)) & 3) -----------------------------------------------
   long long b_off[B_PIECES];
@@ -290,19 +261,10 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
     const int woff = DGRAD ? (((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + cbase) : (int)k0;
     const uint32_t bit = 1u << tap;
     char* stage = smem + buf * STAGE_BYTES;
-    if constexpr (APL) {
-      const bf16_t* src3 = reinterpret_cast<const bf16_t*>(p.src3);
-#pragma unroll
-      for (int i = 0; i < AP_PIECES; ++i) {
-        const void* pa = (ap_mask[i] & bit) ? (const void*)(src3 + (ap_off[i] + delta)) : (const void*)zero;
-        __builtin_amdgcn_global_load_lds((gbl_void*)pa, (lds_void*)(stage + ap_lds[i]), 16, 0, 0);
-      }
-    } else {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const float* pa = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
       __builtin_amdgcn_global_load_lds((gbl_void*)pa, (lds_void*)(stage + (i * RPP + wave * 8) * 128), 16, 0, 0);
-    }
     }
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i)
@@ -431,39 +393,6 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
     constexpr int JH = TN > 4 ? 4 : TN;                                // filter fragments held in registers at a time
 
     if (nkt > 0) issue_tile(0, 0);
-    if constexpr (TMW == 4) {
-      // One wave per SIMD: ALL fragments of the K-tile go to registers first (8 activation + 3 TN filter reads), then the
-      // next tile's DMA is issued (the compiler puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA
-      // issue, so no read may come after it), and the 24 TN MFMAs of the tile cover its latency.
-      for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const char* tA = smem + (kt & 1) * STAGE_BYTES;
-        const char* tB = tA + A_BYTES;
-        uint4 fa[2][TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-            fa[ks][i] = *reinterpret_cast<const uint4*>(tA + x6p_a_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
-        uint4 bp[TN][3];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int part = 0; part < 3; ++part)
-            bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
-        if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
-        uint4 ap[TM][3];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
-      }
-    } else
     for (int kt = 0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -471,19 +400,11 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
       const char* tB = tA + A_BYTES;
       uint4 fa[2][TM];
       uint4 ap[TM][3];
-      if constexpr (APL) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int part = 0; part < 3; ++part)
-            ap[i][part] = *reinterpret_cast<const uint4*>(tA + part * AP_BYTES + (wave * WROWS + i * 16) * 64 + b_frag);
-      } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           fa[ks][i] = *reinterpret_cast<const uint4*>(tA + x6p_a_off(wave * WROWS + i * 16 + fr, 2 * fq + ks));
-      }
       uint4 bp[JH][3];
 #pragma unroll
       for (int j = 0; j < JH; ++j)
@@ -491,23 +412,8 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
         for (int part = 0; part < 3; ++part)
           bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
       if constexpr (TN <= 4) { if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1); }
-      if constexpr (NOL) {      // experiment: relu(x * scale[c] + shift[c]) on the lane's 8 reduction elements (channels)
-        const int cb = (kt * BKE) % p.sC + 8 * fq;
-        const float4 s0 = *reinterpret_cast<const float4*>(p.nol_scale + cb), s1 = *reinterpret_cast<const float4*>(p.nol_scale + cb + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(p.nol_shift + cb), h1 = *reinterpret_cast<const float4*>(p.nol_shift + cb + 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          uint4& lo = fa[0][i]; uint4& hi = fa[1][i];
-          lo.x = __float_as_uint(fmaxf(__uint_as_float(lo.x) * s0.x + h0.x, 0.f)); lo.y = __float_as_uint(fmaxf(__uint_as_float(lo.y) * s0.y + h0.y, 0.f));
-          lo.z = __float_as_uint(fmaxf(__uint_as_float(lo.z) * s0.z + h0.z, 0.f)); lo.w = __float_as_uint(fmaxf(__uint_as_float(lo.w) * s0.w + h0.w, 0.f));
-          hi.x = __float_as_uint(fmaxf(__uint_as_float(hi.x) * s1.x + h1.x, 0.f)); hi.y = __float_as_uint(fmaxf(__uint_as_float(hi.y) * s1.y + h1.y, 0.f));
-          hi.z = __float_as_uint(fmaxf(__uint_as_float(hi.z) * s1.z + h1.z, 0.f)); hi.w = __float_as_uint(fmaxf(__uint_as_float(hi.w) * s1.w + h1.w, 0.f));
-        }
-      }
-      if constexpr (!APL) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
-      }
+      for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -607,29 +513,17 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 4 ? 1 : 2)) conv_x6p_kernel(c
   }
 }
 
-template <int TN, int NW, int MF, int TMW = 2>
+template <int TN, int NW, int MF>
 static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
-  constexpr int BN = TN * 16, BM = 16 * TMW * NW;
+  constexpr int BN = TN * 16, BM = 32 * NW;
   p.tilesM = (p.M - p.m_off + BM - 1) / BM;
   p.tilesN = (p.dC + BN - 1) / BN;
-  static const int pad = [] { const char* e = getenv("DPA_X6P_LDS_PAD"); return e ? atoi(e) : 0; }();      // residency experiments
-  size_t lds = (size_t)2 * (BM * 128 + 3 * BN * 64) + pad;
+  size_t lds = (size_t)2 * (BM * 128 + 3 * BN * 64);
   const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
-  if constexpr (TMW == 4) {
-    if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, false, false, 4>), grid, block, lds, s, p);
-    else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, false, false, 4>), grid, block, lds, s, p);
-    return;
-  } else {
   if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF>), grid, block, lds, s, p);
-  else if (p.src3) {
-    const size_t lds3 = (size_t)2 * (3 * BM * 64 + 3 * BN * 64);
-    hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, false, true>), grid, block, lds3 > epi ? lds3 : epi, s, p);
-  }
-  else if (p.nol_scale) hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, true>), grid, block, lds, s, p);
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
-  }
 }
 
 // Fewest tiles for which the pre-split kernel is taken (DPA_X6P_MIN_TILES, default 96: profiles/r2_x6p_small_batch_sweep.txt).  v >= 0 sets it and returns the
@@ -647,14 +541,11 @@ DPA_API int dpa_x6p_min_tiles(int v) {
 static long long x6p_tiles(const ConvParams& p, bool narrow) {
   return (long long)((p.M + 127) / 128) * ((p.dC + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
 }
-// which: 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_TALL_MIN (default 512), 3 = DPA_X6P_TALL (default 0: the
-// 256-row tile is an experiment that lost).  v >= 0 sets the knob and returns
-// the previous value (the kernel tests steer small shapes to each variant with it); v < 0 only reads it.
+// which: 1 = DPA_X6P_NARROW_BELOW (default 512).  v >= 0 sets the knob and returns the previous value (the kernel tests
+// steer small shapes to each tile width with it); v < 0 only reads it.
 DPA_API int dpa_x6p_knob(int which, int v) {
-  static int cur[4] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
-                          [] { const char* e = getenv("DPA_X6P_TALL_MIN"); return e ? atoi(e) : 512; }(),
-                          [] { const char* e = getenv("DPA_X6P_TALL"); return e ? atoi(e) : 0; }()};
-  if (which < 1 || which > 3) return -1;
+  static int cur[2] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }()};
+  if (which != 1) return -1;
   const int prev = cur[which];
   if (v >= 0) cur[which] = v;
   return prev;
@@ -683,14 +574,7 @@ DPA_API int dpa_x6p_plausible(long long M, int dC) {
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   p.m_off = 0; p.stats_row0 = 0;
-  static const int apl_tn = [] { const char* e = getenv("DPA_X6PP_TN"); return e ? atoi(e) : 8; }();      // experiment: tile width with src3
-  // 256-row tile (one block per CU): opt-in experiment (DPA_X6P_TALL=1, for problems with at least DPA_X6P_TALL_MIN such
-  // tiles) - measured 10-15 % SLOWER than the 128-row tile on every ResNet-50 layer (profiles/r2_x6p_tall_tile.txt)
-  const int tall = dpa_x6p_knob(3, -1);
-  const int tall_min = dpa_x6p_knob(2, -1);
-  const long long tall_tiles = (long long)((p.M + 255) / 256) * ((p.dC + 127) / 128);
-  if (x6p_narrow(p) || (p.src3 && apl_tn == 4)) x6p_launch<4, 4, 16>(p, dgrad, s);
-  else if (tall && !p.src3 && !p.nol_scale && tall_tiles >= tall_min) x6p_launch<8, 4, 16, 4>(p, dgrad, s);
-  else                                       x6p_launch<8, 4, 16>(p, dgrad, s);
+  if (x6p_narrow(p)) x6p_launch<4, 4, 16>(p, dgrad, s);
+  else               x6p_launch<8, 4, 16>(p, dgrad, s);
   return p.tilesM;
 }

@@ -6,17 +6,26 @@
 // correctly when lr (StepLR) or the step changes.
 #include "common.h"
 
-// hyper layout (floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step (as float)
-//                        [6]=momentum [7]=grad_scale (1/world_size folded in here)
+// hyper layout (12 floats): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=weight_decay [5]=step (as float)
+//                           [6]=momentum [7]=grad_scale (1/world_size folded in here)
+//                           [8]=float(1-beta1) [9]=float(1-beta2) [10]=beta1-(double)float(beta1) [11]=same for beta2
+// The last four exist so that the kernel can reproduce torch.optim.Adam's scalar handling to the ulp (nn/optim.py:
+// make_hyper): torch keeps the betas as Python doubles - the increments use float(1 - beta) (0.001f, not 1 - 0.999f =
+// 0.00099998713), the bias corrections 1 - beta**step are evaluated in double - and only the per-element arithmetic is
+// fp32.  With everything derived from float(beta2) instead, the update differed from torch's by 1e-5 relative
+// (27 fp32 ulps on a parameter of the update's own size; tests/test_gpu_ops.py::test_optimizers_match_torch now bounds
+// it at 2).  Built without -ffast-math (csrc/build.py).
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ p16, const float* __restrict__ hyper,
                                                    long long n) {
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
-  const float step = hyper[5] + 1.0f, gs = hyper[7];
-  const float bc1 = 1.0f - powf(b1, step);
-  const float bc2s = sqrtf(1.0f - powf(b2, step));
-  const float step_size = lr / bc1;
+  const float lr = hyper[0], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float gs = hyper[7], omb1 = hyper[8], omb2 = hyper[9];
+  const double step = (double)hyper[5] + 1.0;
+  const double b1d = (double)hyper[1] + (double)hyper[10], b2d = (double)hyper[2] + (double)hyper[11];
+  const double bc1 = 1.0 - pow(b1d, step);
+  const float bc2s = (float)sqrt(1.0 - pow(b2d, step));
+  const float step_size = (float)((double)lr / bc1);
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (; i + 3 < n; i += stride) {
@@ -28,10 +37,10 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float gr = ga[k] * gs + wd * pa[k];
-      ma[k] = b1 * ma[k] + (1.0f - b1) * gr;
-      va[k] = b2 * va[k] + (1.0f - b2) * gr * gr;
+      ma[k] = ma[k] + omb1 * (gr - ma[k]);            // torch: exp_avg.lerp_(grad, 1 - beta1)
+      va[k] = b2 * va[k] + omb2 * gr * gr;            // torch: exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
       float denom = sqrtf(va[k]) / bc2s + eps;
-      pa[k] -= step_size * (ma[k] / denom);
+      pa[k] -= step_size * (ma[k] / denom);           // torch: param.addcdiv_(exp_avg, denom, value=-step_size)
     }
     *reinterpret_cast<float4*>(p + i) = pp;
     *reinterpret_cast<float4*>(m + i) = mm;
@@ -47,8 +56,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   if (i < n) {
     for (long long j = i; j < n; ++j) {
       float gr = g[j] * gs + wd * p[j];
-      float mj = b1 * m[j] + (1.0f - b1) * gr;
-      float vj = b2 * v[j] + (1.0f - b2) * gr * gr;
+      float mj = m[j] + omb1 * (gr - m[j]);
+      float vj = b2 * v[j] + omb2 * gr * gr;
       m[j] = mj; v[j] = vj;
       float pj = p[j] - step_size * (mj / (sqrtf(vj) / bc2s + eps));
       p[j] = pj;

@@ -13,7 +13,19 @@ from .. import ops
 from .engine import ParamStore
 
 # hyper vector slots (csrc/hip/optim.hip)
-LR, B1, B2, EPS, WD, STEP, MOM, GSCALE = range(8)
+LR, B1, B2, EPS, WD, STEP, MOM, GSCALE, OMB1, OMB2, B1LO, B2LO = range(12)
+
+
+def make_hyper(lr, beta1, beta2, eps, weight_decay, step, momentum, grad_scale, device=None):
+    """The 12-float hyper-parameter vector of the optimizer kernels.  Slots 8-11 carry what torch.optim keeps in Python
+    doubles: float(1 - beta) for the moment increments and the low parts beta - float(beta), from which the kernel
+    rebuilds the double betas for the bias corrections (csrc/hip/optim.hip)."""
+    import struct
+
+    def f32(x):
+        return struct.unpack("f", struct.pack("f", x))[0]
+    return torch.tensor([lr, beta1, beta2, eps, weight_decay, step, momentum, grad_scale, 1.0 - beta1, 1.0 - beta2,
+                         beta1 - f32(beta1), beta2 - f32(beta2)], dtype=torch.float32, device=device)
 
 
 class ArenaOptimizer:
@@ -23,8 +35,8 @@ class ArenaOptimizer:
             raise ValueError(f"Invalid optimizer {kind!r}")
         self.store, self.kind = store, kind
         dev = store.device
-        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0, momentum if kind == "SGD" else 0.0,
-                                   grad_scale], dtype=torch.float32, device=dev)
+        self.hyper = make_hyper(lr, betas[0], betas[1], eps, weight_decay, 0.0, momentum if kind == "SGD" else 0.0,
+                                grad_scale, device=dev)
         self.m = torch.zeros_like(store.p)
         self.v = torch.zeros_like(store.p) if kind == "adam" else None
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, momentum=momentum)

@@ -52,8 +52,7 @@ def weight_prep(table, nsegs, total_chunks, dtype):
                         native.stream_ptr())
 
 
-def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None, _nol=None, _x3=None,
-               oscale=None):
+def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=None, stats_shift=None, w3=None, oscale=None):
     """y = conv(x, w) (+bias) (+addend) (relu).  stats: fp32 [rows, 2, Cout] slab written with per-block
     (sum, sumsq) of the stored outputs minus the per-channel `stats_shift` (0 if None); rows = stats_rows(M, Cout).
     oscale: fp32 per-output-channel multiplier applied to the accumulator before the bias (folded inference BatchNorm)."""
@@ -68,10 +67,6 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     p.stats_shift = native.ptr(stats_shift)
     p.oscale = native.ptr(oscale)
     p.wgt3, p.wgt3_plane = native.ptr(w3), w.numel()
-    if _x3 is not None:           # experiment only (scripts/bench_x6pp.py): the activation pre-split into planes too
-        p.src3, p.src3_plane = VP(_x3.data_ptr()), x.numel()
-    if _nol is not None:          # experiment only (scripts/bench_norm_on_load.py): normalise-on-load in the x6p kernel
-        p.nol_scale, p.nol_shift = VP(_nol[0].data_ptr()), VP(_nol[1].data_ptr())
     p.sN, p.sH, p.sW, p.sC = x.shape
     p.s_cs, p.s_co = _check_nhwc(x, "x"), 0
     p.dH, p.dW, p.dC = y.shape[1], y.shape[2], y.shape[3]

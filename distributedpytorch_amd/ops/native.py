@@ -15,7 +15,8 @@ import os
 
 import torch  # noqa: F401  (must precede the CDLL of the HIP library)
 
-_LIBDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
+# DPA_LIB_DIR: an A/B build of the native libraries (python -m distributedpytorch_amd.csrc.build --libdir DIR -D...)
+_LIBDIR = os.environ.get("DPA_LIB_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
 _hip = None
 _host = None
 
@@ -33,7 +34,7 @@ class ConvParams(ctypes.Structure):
     _fields_ = [
         ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP), ("stats_shift", VP), ("wgt3", VP), ("wgt3_plane", I64),
         ("bnr_x", VP), ("bnr_y", VP), ("bnr_mean", VP), ("bnr_invstd", VP), ("bnr_mscale", VP), ("bnr_mshift", VP), ("bnr_slab", VP),
-        ("bnr_cs", I32), ("bnr_y_cs", I32), ("bnr_row0", I32), ("bnr_pad", I32), ("nol_scale", VP), ("nol_shift", VP), ("src3", VP), ("src3_plane", I64), ("oscale", VP),
+        ("bnr_cs", I32), ("bnr_y_cs", I32), ("bnr_row0", I32), ("bnr_pad", I32), ("oscale", VP),
         ("sN", I32), ("sH", I32), ("sW", I32), ("sC", I32), ("s_cs", I32), ("s_co", I32),
         ("dH", I32), ("dW", I32), ("dC", I32), ("d_cs", I32), ("d_co", I32),
         ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),

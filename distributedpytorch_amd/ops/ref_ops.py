@@ -373,15 +373,17 @@ def ce_loss(logits, labels, num_classes, out, accum=None, dlogits=None, class_w=
 # ----------------------------------------------------------------------------------------- optimizer
 def adam_step(p, g, m, v, p16, hyper, lo=0, hi=None):
     hi = p.numel() if hi is None else hi
-    lr, b1, b2, eps, wd, step, _, gs = [float(h) for h in hyper]
+    h = [float(x) for x in hyper]
+    lr, b1, b2, eps, wd, step, _, gs, omb1, omb2 = h[:10]
+    b1d, b2d = b1 + h[10], b2 + h[11]          # the double betas (nn/optim.py: make_hyper)
     step += 1
     gr = g[lo:hi] * gs
     if wd:
         gr = gr + wd * p[lo:hi]
-    m[lo:hi].mul_(b1).add_(gr, alpha=1 - b1)
-    v[lo:hi].mul_(b2).addcmul_(gr, gr, value=1 - b2)
-    bc1 = 1 - b1 ** step
-    bc2s = math.sqrt(1 - b2 ** step)
+    m[lo:hi].lerp_(gr, omb1)
+    v[lo:hi].mul_(b2).addcmul_(gr, gr, value=omb2)
+    bc1 = 1 - b1d ** step
+    bc2s = math.sqrt(1 - b2d ** step)
     denom = v[lo:hi].sqrt() / bc2s + eps
     p[lo:hi].addcdiv_(m[lo:hi], denom, value=-lr / bc1)
     if p16 is not None:
@@ -390,7 +392,7 @@ def adam_step(p, g, m, v, p16, hyper, lo=0, hi=None):
 
 def sgd_step(p, g, buf, p16, hyper, lo=0, hi=None):
     hi = p.numel() if hi is None else hi
-    lr, _, _, _, wd, step, mu, gs = [float(h) for h in hyper]
+    lr, _, _, _, wd, step, mu, gs = [float(h) for h in hyper[:8]]
     gr = g[lo:hi] * gs
     if wd:
         gr = gr + wd * p[lo:hi]

@@ -59,6 +59,7 @@ class DistributedModel:
         """x: NHWC compute-dtype batch on the device; labels: int64 on the device.  mark(name): optional callback at
         the end of each phase (utils/steplog.py records a HIP event there; never a host sync)."""
         net, red = self.net, self.reducer
+        opt_mark = mark
         mark = mark or (lambda name: None)
         net.train()
         with rng("sync_buffers"):
@@ -78,10 +79,10 @@ class DistributedModel:
             self._arena_end(prev)
         mark("bwd")
         with rng("wait+optimizer"):
-            red.finish_and_step()
+            red.finish_and_step(opt_mark)
         from .. import ops
         ops.rng_advance(net.rng)
-        mark("wait_opt")
+        mark("opt")
         self._need_buffer_sync = True
 
     def timed_train_step(self, x, labels):

@@ -184,8 +184,10 @@ class GradReducer:
         else:
             self._works[bi] = dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def finish_and_step(self):
-        """Wait for each bucket in ready order and launch its optimizer update right away."""
+    def finish_and_step(self, mark=None):
+        """Wait for each bucket in ready order and launch its optimizer update right away.  mark(name): optional phase
+        callback (utils/steplog.py): 'wait' after each bucket's wait, 'opt' after each optimizer launch - so the step log
+        can tell exposed all-reduce time from optimizer time."""
         self.store.fence_buffers()          # (no-op unless no BatchNorm ran this step)
         stream = self._stream()
         for bi, bk in enumerate(self.buckets):
@@ -200,7 +202,11 @@ class GradReducer:
             w = self._works[bi]
             if w is not None and w != "native":
                 w.wait()                       # stream-level wait on GPU; blocks on gloo
+            if mark is not None:
+                mark("wait")
             self.opt.step_range(bk["lo"], bk["hi"])
+            if mark is not None:
+                mark("opt")
         self.opt.finish_step()
 
     # ------------------------------------------------------------------ diagnostics

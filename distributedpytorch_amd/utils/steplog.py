@@ -14,7 +14,7 @@ import time
 
 import torch
 
-PHASES = ("data", "sync", "fwd", "bwd", "wait_opt")
+PHASES = ("data", "sync", "fwd", "bwd", "wait", "opt")
 
 
 class StepLog:
@@ -80,12 +80,13 @@ class StepLog:
                 out = dict(step=rec["step"], epoch=rec["epoch"], loss=round(loss, 6), acc=round(acc, 6),
                            step_ms=round(total, 4),
                            images_per_s=round(rec["n"] * self.world / max(total, 1e-9) * 1e3, 1), world_size=self.world)
-                for name, v in zip(rec["names"], ms):
-                    out[f"{name}_ms"] = round(v, 4)
+                for name, v in zip(rec["names"], ms):      # "wait" and "opt" occur once per gradient bucket: summed
+                    out[f"{name}_ms"] = round(out.get(f"{name}_ms", 0.0) + v, 4)
                 # the two the survey names explicitly: time in the input pipeline, and time on communication that
-                # backward did not hide (buffer broadcast + bucket waits; the waits share their phase with the
-                # fused optimizer launches, and are exactly 0 at world size 1)
+                # backward did not hide = the buffer broadcast's issue + the per-bucket waits for the all-reduces.  The
+                # fused optimizer launches between the waits are timed separately (opt_ms), so comm_ms is exposed
+                # all-reduce time only.
                 out["data_ms"] = out.get("data_ms", 0.0)
-                out["comm_ms"] = round(out.get("sync_ms", 0.0) + (out.get("wait_opt_ms", 0.0) if self.world > 1 else 0.0), 4)
+                out["comm_ms"] = round(out.get("sync_ms", 0.0) + out.get("wait_ms", 0.0), 4)
                 f.write(json.dumps(out) + "\n")
         self.pending = []

@@ -9,6 +9,8 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--only", default="")
+ap.add_argument("--net", default="resnet50", choices=["resnet50", "resnet18_cifar"],
+                help="resnet18_cifar: BASELINE config 4 (ResNet-18 on 32x32 inputs: 3x3 stem, no max-pool; maps 32/16/8/4)")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 # (H, Cin, Cout, k, stride, pad, count)
@@ -20,6 +22,11 @@ LAYERS = [(224, 8, 64, 7, 2, 3, 1),
           (14, 1024, 256, 1, 1, 0, 5), (14, 256, 256, 3, 1, 1, 5),
           (14, 1024, 512, 1, 1, 0, 1), (14, 512, 512, 3, 2, 1, 1), (7, 512, 2048, 1, 1, 0, 3), (14, 1024, 2048, 1, 2, 0, 1),
           (7, 2048, 512, 1, 1, 0, 2), (7, 512, 512, 3, 1, 1, 2)]
+if a.net == "resnet18_cifar":
+    LAYERS = [(32, 8, 64, 3, 1, 1, 1), (32, 64, 64, 3, 1, 1, 4),
+              (32, 64, 128, 3, 2, 1, 1), (16, 128, 128, 3, 1, 1, 3), (32, 64, 128, 1, 2, 0, 1),
+              (16, 128, 256, 3, 2, 1, 1), (8, 256, 256, 3, 1, 1, 3), (16, 128, 256, 1, 2, 0, 1),
+              (8, 256, 512, 3, 2, 1, 1), (4, 512, 512, 3, 1, 1, 3), (8, 256, 512, 1, 2, 0, 1)]
 N = a.batch
 tot = {"fprop": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 def timeit(fn):

@@ -9,12 +9,19 @@ config.py:26-44, classif.py:110,124) is trained twice on ONE MI355X from the SAM
            fp32, the reference's software stack (MIOpen / hipBLASLt kernels)
   engine   this framework (hand-written HIP kernels, fused Adam over the arenas), fp32 and bf16
 
+ACCEPTANCE PATH = the reference's own (classif.py:185-192, `main.py test -f bestmodel-...`): after every epoch the
+validation loss is computed, the parameters of the epoch with the BEST validation loss are kept (the reference's
+bestmodel checkpoint), and the reported test accuracy is that of the best-validation model - not of the last epoch,
+whose accuracy swings by several points from epoch to epoch in every implementation (profiles/r1_mnist_valid_swings.txt).
+Runs are paired by seed (same initial weights, same batches); the summary gives mean +- sd per mode and the PAIRED
+difference against torch with its standard error.
+
 Both consume the batches of the device input pipeline (rotate +-5 deg, random-resized-crop, bilinear 28->224,
 normalise; dataloader.py:101-116) so the comparison isolates the training engine.  There is no network on the box,
 so the digits are the deterministic synthetic MNIST of data/mnist.py (IDX files, same sizes) - "parity unpinned" w.r.t.
 the real MNIST files, which are not available offline.
 
-  python scripts/mnist_parity.py --out gpurun_out/mnist_parity.json [--n-train 60000 --n-test 10000 --epochs 2]
+  python scripts/mnist_parity.py --hard --epochs 4 --seeds 8 --out gpurun_out/mnist_parity.json
 """
 import argparse
 import json
@@ -52,6 +59,14 @@ def run_engine(path, dtype, epochs, batch, seed, init_sd=None):
     dm = DistributedModel(net, Criterion("cross_entropy"), ArenaOptimizer(net.store, "adam", lr=1e-3))
     hist = []
     t0 = time.time()
+    best = (float("inf"), -1, None)
+
+    def test_pass():
+        dm.reset_epoch_metrics()
+        for x, y in ds.iterator["test"]:
+            dm.eval_step(x, y)
+        return dm.epoch_metrics()[1] * 100
+
     for ep in range(epochs):
         ds.sampler["train"].set_epoch(ep)
         dm.reset_epoch_metrics()
@@ -63,13 +78,17 @@ def run_engine(path, dtype, epochs, batch, seed, init_sd=None):
             dm.eval_step(x, y)
         vl, va, _ = dm.epoch_metrics()
         hist.append(dict(epoch=ep + 1, train_loss=tl, train_acc=ta, valid_loss=vl, valid_acc=va))
+        if vl < best[0]:            # the reference's bestmodel checkpoint (classif.py:188-192)
+            best = (vl, ep + 1, (net.store.p.clone(), net.store.buffer_arena.clone()))
         print(f"  engine[{dtype}] epoch {ep + 1}: train {tl:.4f}/{ta * 100:.2f}%  valid {vl:.4f}/{va * 100:.2f}%", flush=True)
-    dm.reset_epoch_metrics()
-    for x, y in ds.iterator["test"]:
-        dm.eval_step(x, y)
-    _, test_acc, _ = dm.epoch_metrics()
+    last_acc = test_pass()
+    net.store.p.copy_(best[2][0])
+    net.store.buffer_arena.copy_(best[2][1])
+    net.store.refresh_compute_copy()
+    best_acc = test_pass()
     torch.cuda.synchronize()
-    return dict(history=hist, test_acc=test_acc * 100, seconds=time.time() - t0), sd0
+    return dict(history=hist, test_acc=best_acc, best_epoch=best[1], best_valid_loss=best[0], last_epoch_test_acc=last_acc,
+                seconds=time.time() - t0), sd0
 
 
 def run_torch(path, epochs, batch, seed, init_sd):
@@ -96,8 +115,10 @@ def run_torch(path, epochs, batch, seed, init_sd):
                 n += 1
         return tot_l / n, tot_a / n
 
+    import copy
     hist = []
     t0 = time.time()
+    best = (float("inf"), -1, None)
     for ep in range(epochs):
         ds.sampler["train"].set_epoch(ep)
         model.train()
@@ -115,11 +136,16 @@ def run_torch(path, epochs, batch, seed, init_sd):
             n += 1
         vl, va = evaluate("valid")
         hist.append(dict(epoch=ep + 1, train_loss=float(sl) / n, train_acc=float(sa) / n, valid_loss=vl, valid_acc=va))
+        if vl < best[0]:
+            best = (vl, ep + 1, copy.deepcopy(model.state_dict()))
         print(f"  torch[fp32] epoch {ep + 1}: train {float(sl) / n:.4f}/{float(sa) / n * 100:.2f}%  valid {vl:.4f}/{va * 100:.2f}%",
               flush=True)
-    _, test_acc = evaluate("test")
+    _, last_acc = evaluate("test")
+    model.load_state_dict(best[2])
+    _, best_acc = evaluate("test")
     torch.cuda.synchronize()
-    return dict(history=hist, test_acc=test_acc * 100, seconds=time.time() - t0)
+    return dict(history=hist, test_acc=best_acc * 100, best_epoch=best[1], best_valid_loss=best[0],
+                last_epoch_test_acc=last_acc * 100, seconds=time.time() - t0)
 
 
 def main():
@@ -133,6 +159,8 @@ def main():
     ap.add_argument("--hard", action="store_true",
                     help="the harder synthetic digits (per-sample stroke variation, overlapping classes): accuracies "
                          "saturate below 100 %, so the comparison discriminates (VERDICT r1 #8)")
+    ap.add_argument("--data-seed", type=int, default=None, help="seed of the synthetic DATASET (default: --seed); lets several "
+                    "invocations with different --seed ranges share one dataset")
     ap.add_argument("--out", default="")
     ap.add_argument("--data", default="")
     a = ap.parse_args()
@@ -140,10 +168,12 @@ def main():
     path = a.data or tempfile.mkdtemp(prefix="dpa_mnist_")
     if not mnist.have_mnist(path) and not mnist.have_synthetic(path):
         t0 = time.time()
-        mnist.generate_synthetic_mnist(path, n_train=a.n_train, n_test=a.n_test, seed=a.seed, hard=a.hard)
+        mnist.generate_synthetic_mnist(path, n_train=a.n_train, n_test=a.n_test, seed=a.seed if a.data_seed is None else a.data_seed,
+                                       hard=a.hard)
         print(f"generated the {'hard ' if a.hard else ''}synthetic digits in {time.time() - t0:.0f}s", flush=True)
     runs = ("torch_fp32", "engine_fp32_exact", "engine_fp32_x6", "engine_bf16")
-    res = {"config": vars(a), "data": ("hard " if a.hard else "") + "synthetic MNIST (data/mnist.py generator; real MNIST is not "
+    res = {"config": vars(a), "acceptance": "test accuracy of the best-validation-loss model (the reference's bestmodel checkpoint, "
+           "classif.py:188-192), paired by seed", "data": ("hard " if a.hard else "") + "synthetic MNIST (data/mnist.py generator; real MNIST is not "
            "available offline: parity unpinned w.r.t. the real files)", "per_seed": []}
 
     def dump():
@@ -178,9 +208,17 @@ def main():
     for k in runs:
         accs = [o[k]["test_acc"] for o in res["per_seed"]]
         vals = [o[k]["history"][-1]["valid_acc"] * 100 for o in res["per_seed"]]
-        summary[k] = dict(test_acc_mean=round(st.mean(accs), 3), test_acc_sd=round(st.stdev(accs), 3) if len(accs) > 1 else None,
+        last = [o[k]["last_epoch_test_acc"] for o in res["per_seed"]]
+        diffs = [o[k]["test_acc"] - o["torch_fp32"]["test_acc"] for o in res["per_seed"]]
+        n = len(accs)
+        summary[k] = dict(test_acc_mean=round(st.mean(accs), 3), test_acc_sd=round(st.stdev(accs), 3) if n > 1 else None,
                           test_acc_min=round(min(accs), 3), test_acc_max=round(max(accs), 3),
+                          paired_diff_vs_torch_mean=round(st.mean(diffs), 3),
+                          paired_diff_vs_torch_sd=round(st.stdev(diffs), 3) if n > 1 else None,
+                          paired_diff_vs_torch_stderr=round(st.stdev(diffs) / n ** 0.5, 3) if n > 1 else None,
+                          last_epoch_test_acc_mean=round(st.mean(last), 3), last_epoch_test_acc_sd=round(st.stdev(last), 3) if n > 1 else None,
                           final_valid_acc_mean=round(st.mean(vals), 3), per_seed_test_acc=[round(v, 2) for v in accs],
+                          best_epochs=[o[k]["best_epoch"] for o in res["per_seed"]],
                           seconds_mean=round(st.mean(o[k]["seconds"] for o in res["per_seed"]), 1))
     res["summary"] = summary
     print(json.dumps(summary), flush=True)

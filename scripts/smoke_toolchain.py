@@ -4,7 +4,8 @@ print("cuda", torch.cuda.is_available(), torch.cuda.get_device_name(0))
 n = 11_181_642
 p = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda")
 m = torch.zeros_like(p); v = torch.zeros_like(p)
-hyper = torch.tensor([1e-3, .9, .999, 1e-8, 0, 0, 0.9, 1.0], device="cuda")
+from distributedpytorch_amd.nn.optim import make_hyper
+hyper = make_hyper(1e-3, .9, .999, 1e-8, 0, 0, 0.9, 1.0, device="cuda")
 pr = torch.nn.Parameter(p.clone()); pr.grad = g.clone()
 opt = torch.optim.Adam([pr], lr=1e-3)
 s = torch.cuda.current_stream().cuda_stream

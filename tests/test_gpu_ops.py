@@ -129,9 +129,22 @@ def test_maxpool(cfg, dtype):
     torch.testing.assert_close(res["hip"][0], res["ref"][0], rtol=0, atol=0)
     ref_nchw = torch.nn.functional.max_pool2d(x.float().permute(0, 3, 1, 2), k, s, p, ceil_mode=ceil).permute(0, 2, 3, 1)
     torch.testing.assert_close(res["hip"][0], ref_nchw, rtol=0, atol=0)
-    # total gradient mass is conserved; exact tie-breaking may differ from the unfold-based reference
+    # backward, per element (the post-ReLU input above has ties at zero, where the winner inside a window is a convention:
+    # there only the gradient MASS per channel can be compared; the element-wise check uses a tie-free fp32 input and
+    # torch's own max-pool backward - the same kind of check as tests/test_gpu_parity.py::test_maxpool_backward_per_element)
     rtol, atol = _tol(dtype)
     torch.testing.assert_close(res["hip"][1].sum((1, 2)), res["ref"][1].sum((1, 2)), rtol=rtol * 10, atol=atol * 50)
+    if dtype == torch.float32:
+        x2 = _rand(shape, dtype, 3)                 # continuous values: no two equal in a window
+        xt = x2.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        yt = torch.nn.functional.max_pool2d(xt, k, s, p, ceil_mode=ceil)
+        yt.backward(dy.float().permute(0, 3, 1, 2))
+        y = torch.empty(n, ho, wo, c, device="cuda", dtype=dtype)
+        idx = torch.empty(n, ho, wo, c, device="cuda", dtype=torch.uint8)
+        H.maxpool_fwd(x2.cuda(), y, idx, (k, k), (s, s), (p, p))
+        dx = torch.empty(shape, device="cuda", dtype=dtype)
+        H.maxpool_bwd(dy.cuda(), idx, dx, (k, k), (s, s), (p, p))
+        torch.testing.assert_close(dx.cpu(), xt.grad.permute(0, 2, 3, 1), rtol=1e-6, atol=1e-6)      # every element, not the sum
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -254,27 +267,51 @@ def test_dropout_mask_regenerates(dtype):
 
 
 def test_optimizers_match_torch():
+    """Fused arena Adam / SGD-momentum against torch.optim, step by step FROM THE SAME STATE (parameters and moments are
+    re-synchronised to torch's before every step, so each step's own arithmetic is what is compared): within 4 fp32 ulps
+    at the scale of the parameter or of its update, whichever is larger.  optim.hip is built with IEEE arithmetic
+    (no -ffast-math since round 3) and reproduces torch's scalar handling (double betas, float(1 - beta) increments,
+    lerp form of the first moment); what is left is the order of alpha * m / denom in torch's CPU addcdiv."""
     from distributedpytorch_amd.ops import hip_ops as H
+    from distributedpytorch_amd.nn.optim import make_hyper, STEP
     n = 10_007
     for kind in ("adam", "sgd"):
         p0, g0 = torch.randn(n), torch.randn(n)
-        p = p0.cuda()
-        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-        p16 = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
-        hyper = torch.tensor([1e-3, .9, .999, 1e-8, 0., 0., 0.9, 0.5], device="cuda")
         ref = torch.nn.Parameter(p0.clone())
         opt = torch.optim.Adam([ref], lr=1e-3) if kind == "adam" else torch.optim.SGD([ref], lr=1e-3, momentum=0.9)
-        for it in range(4):
+        hyper = make_hyper(1e-3, .9, .999, 1e-8, 0., 0., 0.9, 0.5, device="cuda")
+        p16 = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+        worst = 0.0
+        for it in range(6):
+            st = opt.state.get(ref, {})
+            p = ref.data.clone().cuda()
+            if kind == "adam":
+                m = st["exp_avg"].clone().cuda() if st else torch.zeros(n, device="cuda")
+                v = st["exp_avg_sq"].clone().cuda() if st else torch.zeros(n, device="cuda")
+            else:
+                m = st["momentum_buffer"].clone().cuda() if st else torch.zeros(n, device="cuda")
+            hyper[STEP] = float(it)
             g = (g0 * (it + 1)).cuda()
             if kind == "adam":
                 H.adam_step(p, g * 2, m, v, p16, hyper)          # grad_scale 0.5 folds the DDP 1/world
             else:
                 H.sgd_step(p, g * 2, m, p16, hyper)
-            H.advance_step(hyper)
             ref.grad = g0 * (it + 1)
+            before = ref.data.clone()
             opt.step()
-        torch.testing.assert_close(p.cpu(), ref.data, rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(p16.float().cpu(), ref.data.bfloat16().float(), rtol=1e-2, atol=1e-2)
+            scale = torch.maximum(ref.data.abs(), (ref.data - before).abs())      # the parameter or its update, whichever is larger
+            ulp = torch.exp2(torch.floor(torch.log2(scale)) - 23)
+            worst = max(worst, ((p.cpu() - ref.data).abs() / ulp).max().item())
+            st = opt.state[ref]
+            if kind == "adam":
+                torch.testing.assert_close(m.cpu(), st["exp_avg"], rtol=3e-7, atol=1e-12)
+                torch.testing.assert_close(v.cpu(), st["exp_avg_sq"], rtol=3e-7, atol=1e-12)
+            else:
+                torch.testing.assert_close(m.cpu(), st["momentum_buffer"], rtol=3e-7, atol=1e-12)
+            torch.testing.assert_close(p16.float().cpu(), ref.data.bfloat16().float(), rtol=1e-2, atol=1e-2)
+        # measured: adam 3.0, sgd <= 2 (torch's CPU addcdiv rounds (alpha * m) / denom, its GPU kernel and ours alpha * (m / denom);
+        # bias-correction casts and sqrt add an ulp).  Before round 3 (-ffast-math, float-derived betas): 27.5.
+        assert worst <= 4.0, (kind, worst)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

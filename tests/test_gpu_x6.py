@@ -152,6 +152,49 @@ def _planes(w):
     return hip_conv.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
 
 
+def test_x6_long_reduction_same_sign_has_no_visible_bias():
+    """Worst case for a BIAS of the x6 arithmetic: a long reduction (K = 3*3*512 = 4608) of products that all have the SAME
+    sign (positive activations times positive filters / gradients) - dropped cross terms and the matrix pipe's internal
+    rounding cannot average out.  Measured against fp64 the signed MEAN relative error of each pass must stay under two
+    fp32 ulps and the per-element error inside the exact path's envelope.  (This test is what rejected the truncating
+    operand split of round 3 - conv_common.h, DPA_SPLIT_TRUNC: mean error -3.5e-6 in fprop, for no speed.)"""
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    N, H, W, C, K, k = 16, 14, 14, 512, 128, 3
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.rand(N, H, W, C, device="cuda", generator=g) + 0.01
+    w = torch.rand(K, k, k, C, device="cuda", generator=g) + 0.01
+    dy = torch.rand(N, H, W, K, device="cuda", generator=g) + 0.01
+    xd, wd, dyd = x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double()
+    refs = {"fprop": F.conv2d(xd, wd, padding=1), "dgrad": torch.nn.grad.conv2d_input((N, C, H, W), wd, dyd, padding=1),
+            "wgrad": torch.nn.grad.conv2d_weight(xd, (K, C, k, k), dyd, padding=1)}
+    res = {}
+    prev = set_fp32_mode("exact")
+    try:
+        for mode in ("exact", "x6"):
+            set_fp32_mode(mode)
+            y = torch.empty(N, H, W, K, device="cuda")
+            wt = w.permute(3, 1, 2, 0).contiguous()
+            hip_conv.conv_fprop(x, w, y, (1, 1), (1, 1), w3=_planes(w) if mode == "x6" else None)
+            dx = torch.empty(N, H, W, C, device="cuda")
+            hip_conv.conv_dgrad(dy, wt, dx, (1, 1), (1, 1), wt3=_planes(wt) if mode == "x6" else None)
+            dw = torch.empty(K, k, k, C, device="cuda")
+            ws = torch.empty(hip_conv.wgrad_workspace_numel(K, k * k * C), device="cuda")
+            hip_conv.conv_wgrad(dy, x, dw, (k, k), (1, 1), (1, 1), workspace=ws)
+            for what, out in (("fprop", y), ("dgrad", dx), ("wgrad", dw)):
+                rel = (out.permute(0, 3, 1, 2).double() - refs[what]) / refs[what]
+                res[(mode, what)] = (rel.mean().item(), rel.abs().max().item())
+    finally:
+        set_fp32_mode(prev)
+    for what in ("fprop", "dgrad", "wgrad"):
+        bias, worst = res[("x6", what)]
+        e_bias, e_worst = res[("exact", what)]
+        # measured (round-to-nearest split): fprop -9e-8 through the general kernel (the bf16 MFMA's internal accumulation
+        # rounds towards zero a little), dgrad / wgrad smaller; the exact path +-1e-9.  2e-7 = under two fp32 ulps.
+        assert abs(bias) < 2e-7, (what, res)
+        assert worst < max(2.0 * e_worst, 4e-7), (what, res)
+
+
 def test_split3_planes_are_exact_and_in_plane_order():
     """p0 + p1 + p2 == w bit for bit (three bf16 parts cover the 24-bit significand); planes in element order."""
     g = torch.Generator(device="cuda").manual_seed(8)
