@@ -201,7 +201,8 @@ def worker(args):
         native_comm = comm.init_native(rank, world, device, os.environ["MASTER_ADDR"],
                                        int(os.environ["MASTER_PORT"]) + 16 * int(os.environ.get("DPA_BENCH_ATTEMPT", "0")),
                                        timeout_s=float(os.environ.get("DPA_COLLECTIVE_TIMEOUT_S", "120")),
-                                       rendezvous_timeout_s=120.0, create_for_single_rank=True)
+                                       rendezvous_timeout_s=120.0, create_for_single_rank=True,
+                                       bringup_timeout_s=float(os.environ.get("DPA_BRINGUP_TIMEOUT_S", "90")))
     elif world > 1 or force:
         comm.init_process_group(rank, world, device)
     # Known-answer check of the data plane BEFORE anything is timed: every rank contributes rank+1 to an all-reduce

@@ -65,7 +65,7 @@ STORE_PORT_OFFSET = 2          # the store listens on MASTER_PORT + 2 (MASTER_PO
 
 
 def init_native(rank, world_size, device, master_addr=None, master_port=None, timeout_s=600.0, rendezvous_timeout_s=300.0,
-                transport=None, create_for_single_rank=False, watchdog=None, exit_grace_s=None):
+                transport=None, create_for_single_rank=False, watchdog=None, exit_grace_s=None, bringup_timeout_s=None):
     """Bring up the native communicator.  Returns it (None at world size 1 unless `create_for_single_rank`)."""
     global _NATIVE, _STORE
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver stack
@@ -83,7 +83,7 @@ def init_native(rank, world_size, device, master_addr=None, master_port=None, ti
         store.announce_and_wait(rank, world_size, tag="join")
         store.timeout_s = timeout_s
     nc = NativeComm(store, rank, world_size, device, transport=transport, timeout_s=timeout_s, master_addr=addr,
-                    watchdog=watchdog, exit_grace_s=exit_grace_s)
+                    watchdog=watchdog, exit_grace_s=exit_grace_s, bringup_timeout_s=bringup_timeout_s)
     _NATIVE, _STORE = nc, store
     logging.debug(f"native communicator up: {nc.name} rank={rank}/{world_size}")
     return nc

@@ -44,6 +44,50 @@ class CommError(RuntimeError):
     pass
 
 
+class _BringupGuard:
+    """Bounds the one blocking call the collective watchdog cannot cover: the transport's own bring-up (ncclCommInitRank
+    exchanges addresses and opens the xGMI / network connections of ALL ranks and simply blocks until every rank has
+    called it).  A timer thread - ctypes releases the GIL during the call - prints which ranks have finished their
+    bring-up and which have not (each rank sets `up/<gen>/<rank>` in the store right after its call returns) and ends
+    the process with status 111: a process stuck inside RCCL cannot be unwound, only replaced (the launcher, or
+    bench.py's supervisor, then tears the job down / falls back)."""
+
+    def __init__(self, what, store, rank, world, timeout_s, key):
+        import threading
+        self.what, self.store, self.rank, self.world, self.timeout_s, self.key = what, store, rank, world, timeout_s, key
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def __enter__(self):
+        if self.timeout_s and self.timeout_s > 0:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        if exc[0] is None and self.store is not None:
+            self.store.set(f"{self.key}/{self.rank}", b"1")
+        return False
+
+    def _run(self):
+        if self._done.wait(self.timeout_s):
+            return
+        import sys
+        up, missing = [], []
+        try:
+            probe = self.store.new_client(timeout_s=2.0) if self.store is not None else None
+            lib = native.host_lib()
+            for r in range(self.world):
+                ok = probe is not None and lib.dpa_store_check(ctypes.c_void_p(probe), f"{self.key}/{r}".encode()) == 0
+                (up if ok else missing).append(r)
+        except Exception:       # noqa: BLE001 - diagnosis only
+            pass
+        print(f"[dpa comm bring-up] {self.what} on rank {self.rank} of {self.world} did not return within {self.timeout_s:.0f} s; "
+              f"ranks whose bring-up has finished: {up}, not finished: {missing}.  Ending the process (exit 111).",
+              file=sys.stderr, flush=True)
+        os._exit(111)
+
+
 def _local_addr_towards(host):
     """The address of the interface that routes to `host` (what peers should connect to)."""
     try:
@@ -69,7 +113,7 @@ class NativeComm:
     exit_grace_s < 0: never end the process (tests)."""
 
     def __init__(self, store, rank, world, device, transport=None, timeout_s=600.0, master_addr="127.0.0.1",
-                 watchdog=None, exit_grace_s=None):
+                 watchdog=None, exit_grace_s=None, bringup_timeout_s=None):
         self.lib = comm_lib()
         self.rank, self.world, self.store = rank, world, store
         self.device = torch.device(device)
@@ -84,6 +128,13 @@ class NativeComm:
         self._hb_client = None
         self.h = None
         dev_index = (self.device.index or 0) if on_gpu else -1
+        if bringup_timeout_s is None:
+            bringup_timeout_s = float(os.environ.get("DPA_BRINGUP_TIMEOUT_S", "0") or 0) or min(float(timeout_s), 300.0)
+        gen_all = 0
+        if store is not None:
+            gen_all = store.bringup_generation = getattr(store, "bringup_generation", 0) + 1
+        guard = lambda what: _BringupGuard(what, store if world > 1 else None, rank, world, bringup_timeout_s if world > 1 else 0,   # noqa: E731
+                                           f"up/{gen_all}")
         if on_gpu:
             # Load the kernel library's code object before the communicator exists (defensive; docs/COMM.md: the order
             # was suspected in round 1 and cleared by the round-2 experiment).
@@ -107,7 +158,8 @@ class NativeComm:
                     store.set(id_key, buf.raw)
             else:
                 buf.raw = store.get(id_key)
-            self.h = self.lib.dpa_comm_init(buf, world, rank, dev_index)
+            with guard("ncclCommInitRank"):
+                self.h = self.lib.dpa_comm_init(buf, world, rank, dev_index)
             if not self.h:
                 raise CommError(f"RCCL communicator bring-up failed: {self.lib.dpa_comm_create_error().decode()}")
         elif self.transport == "mesh":
@@ -121,7 +173,8 @@ class NativeComm:
                 self._check(self.lib.dpa_comm_mesh_export(ctypes.c_void_p(self.h), blob), "mesh export")
                 store.set(f"meshcomm/handles{rank}", blob.raw)
                 everyone = b"".join(store.get(f"meshcomm/handles{r}") for r in range(world))
-                self._check(self.lib.dpa_comm_mesh_connect(ctypes.c_void_p(self.h), everyone), "mesh connect")
+                with guard("hipIpcOpenMemHandle (mesh connect)"):
+                    self._check(self.lib.dpa_comm_mesh_connect(ctypes.c_void_p(self.h), everyone), "mesh connect")
         elif self.transport == "tcp":
             self.h = self.lib.dpa_comm_init_tcp(world, rank, dev_index)
             if not self.h:

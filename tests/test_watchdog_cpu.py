@@ -163,3 +163,39 @@ def test_unresolvable_master_addr_fails_at_once():
     except RuntimeError as e:
         raised = str(e)
     assert "cannot resolve" in raised and time.time() - t0 < 10
+
+
+_BRINGUP = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["DPA_ROOT"])
+import torch
+from distributedpytorch_amd.parallel.store import TCPStore
+from distributedpytorch_amd.parallel.native_comm import _BringupGuard
+rank, port = int(sys.argv[1]), int(sys.argv[2])
+store = TCPStore("127.0.0.1", port, is_master=(rank == 0), timeout_s=30)
+store.announce_and_wait(rank, 2, tag="join")
+with _BringupGuard("ncclCommInitRank", store, rank, 2, 1.5, "up/1"):
+    if rank == 1:
+        time.sleep(60)          # "blocked inside the transport's bring-up": the peer is there, this call never returns
+time.sleep(6)                   # rank 0: finished its bring-up, stays around (it hosts the store)
+print("RANK0 DONE")
+'''
+
+
+def test_transport_bringup_is_bounded_and_says_who_finished(tmp_path):
+    """ncclCommInitRank blocks until every rank has called it and has no timeout of its own; the collective watchdog does not
+    exist yet at that point.  The bring-up guard ends a process stuck there with status 111 and names the ranks whose
+    bring-up has / has not finished."""
+    path = tmp_path / "bringup.py"
+    path.write_text(_BRINGUP)
+    port = _free_port()
+    env = dict(os.environ, DPA_ROOT=ROOT)
+    procs = [subprocess.Popen([sys.executable, str(path), str(r), str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    t0 = time.time()
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert procs[1].returncode == 111, (procs[1].returncode, outs[1][1][-800:])
+    assert time.time() - t0 < 30
+    assert "ncclCommInitRank on rank 1 of 2 did not return within 2 s" in outs[1][1] or "did not return within 1 s" in outs[1][1], outs[1][1]
+    assert "finished: [0], not finished: [1]" in outs[1][1], outs[1][1]
+    assert procs[0].returncode == 0 and "RANK0 DONE" in outs[0][0]
