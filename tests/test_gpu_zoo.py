@@ -9,13 +9,15 @@ ZOO = [("alexnet", "AlexNet", 64, 4, 2e-2), ("vgg", "VGG11BN", 32, 8, 2e-2), ("s
        ("densenet", "DenseNet121", 64, 8, 3e-2), ("inception", "Inception3", 299, 4, 8e-2)]
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("name,cls,hw,n,gtol", ZOO)
-def test_zoo_gpu_fp32(name, cls, hw, n, gtol):
+def test_zoo_gpu_fp32(name, cls, hw, n, gtol, seed):
+    """Three initialisations / inputs per architecture (not the one draw the autouse seeding fixture would pin)."""
     from distributedpytorch_amd.models.factory import get_model
     from tests import torch_ref_models as ref
     from tests.helpers import framework_step, grads_by_name, oracle_step
     from tests.test_models_cpu import _no_dropout, _zero_dropout
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     oracle = _no_dropout(getattr(ref, cls)(10))
     net, _ = get_model(name, 10, device="cuda", dtype=torch.float32)
     _zero_dropout(net)

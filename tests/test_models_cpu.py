@@ -54,9 +54,13 @@ def _zero_dropout(net):
     walk(net.net, set())
 
 
-def _compare_zoo(name, oracle, hw, n, gtol=2e-2, small_input=False):
-    """Parity with dropout disabled on both sides (masks come from different RNG streams by design)."""
-    torch.manual_seed(0)
+def _compare_zoo(name, oracle, hw, n, gtol=2e-2, small_input=False, seed=0):
+    """Parity with dropout disabled on both sides (masks come from different RNG streams by design).
+    `oracle`: a module, or a callable building one (then built under `seed`, so a test can be parametrised over several
+    initialisations instead of relying on the one draw the autouse seeding fixture pins - ADVICE r2)."""
+    torch.manual_seed(seed)
+    if not isinstance(oracle, torch.nn.Module):
+        oracle = oracle()
     net, _ = get_model(name, 10, device="cpu", small_input=small_input)
     _zero_dropout(net)
     _no_dropout(oracle)
@@ -75,11 +79,21 @@ def _compare_zoo(name, oracle, hw, n, gtol=2e-2, small_input=False):
     assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
     g = grads_by_name(net)
     gmax = max(p.grad.norm().item() for p in oracle.parameters())
+    # the same step in torch's OWN fp32: where the problem is ill-conditioned (a ReLU pre-activation at the rounding level,
+    # BatchNorm over 8 values at 1x1 spatial size) any fp32 implementation misses a fixed bound for some draws - such a
+    # parameter passes if our distance to fp64 is within twice torch-fp32's own distance to fp64
+    import copy
+    o32 = copy.deepcopy(oracle).float()
+    for q in o32.parameters():
+        q.grad = None
+    oracle_step(o32, x, y)
+    g32 = {k: q.grad.detach() for k, q in o32.named_parameters()}
     for k, p in oracle.named_parameters():
         v = p.grad.float()
         err = (g[k] - v).norm().item()
+        err32 = (g32[k] - v).norm().item()
         # a conv bias followed by BatchNorm has an exactly-zero gradient: only absolute error is meaningful there
-        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax, (k, err, v.norm().item())
+        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax or err < 2 * err32, (k, err, err32, v.norm().item())
     # BatchNorm running statistics were updated like torch's, and eval mode uses them
     mine2 = net.state_dict(prefix="")
     for k, v in oracle.state_dict().items():
@@ -102,8 +116,12 @@ def test_squeezenet_parity():
     _compare_zoo("squeezenet", ref.SqueezeNet10(10), 64, 4)
 
 
-def test_densenet121_parity():
-    _compare_zoo("densenet", ref.DenseNet121(10), 32, 8)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
+def test_densenet121_parity(seed):
+    """Five initialisations / inputs, not one lucky draw: at 32x32 the last dense block runs BatchNorm over 8 values per
+    channel (1x1 spatial, batch 8) - the test that failed one run in six before the bound was tied to torch-fp32's own
+    distance to fp64."""
+    _compare_zoo("densenet", lambda: ref.DenseNet121(10), 32, 8, seed=seed)
 
 
 def test_inception_v3_parity():
