@@ -1,5 +1,13 @@
-"""T3: every architecture of the zoo on the HIP kernels (fp32 exact-MFMA path) against fp64 torch oracles, plus a
-bf16 run of each for finiteness and loss agreement."""
+"""T3: every architecture of the zoo on the HIP kernels, in both fp32 arithmetics, against fp64 torch oracles, plus a bf16
+run of each for finiteness and loss agreement.
+
+With 4-8 images per batch some ReLU pre-activations sit at the rounding level, and WHICH of them end up on the other side
+of zero than in fp64 depends on the implementation's rounding: the exact-fp32 MFMA path flips the same ones as torch's own
+fp32 (its per-parameter errors equal torch-fp32's digit for digit, scripts/diag/densenet_grad_diag.py), so there the
+criterion "within twice torch-fp32's own distance to fp64" covers them; the x6 path rounds differently (not worse:
+tests/test_gpu_x6.py) and flips a DIFFERENT handful - one flipped unit moves every gradient of that one layer by a few per
+cent of its (tiny) norm.  For x6 a few parameters may therefore miss the relative bound, provided each miss is below
+1e-4 of the largest gradient norm in the network."""
 import pytest
 import torch
 
@@ -11,7 +19,7 @@ ZOO = [("alexnet", "AlexNet", 64, 4, 2e-2), ("vgg", "VGG11BN", 32, 8, 2e-2), ("s
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("name,cls,hw,n,gtol", ZOO)
-def test_zoo_gpu_fp32(name, cls, hw, n, gtol, seed):
+def test_zoo_gpu_fp32(name, cls, hw, n, gtol, seed, fp32_mode):
     """Three initialisations / inputs per architecture (not the one draw the autouse seeding fixture would pin)."""
     from distributedpytorch_amd.models.factory import get_model
     from tests import torch_ref_models as ref
@@ -40,12 +48,18 @@ def test_zoo_gpu_fp32(name, cls, hw, n, gtol, seed):
         q.grad = None
     oracle_step(o32, x.cuda(), y.cuda())
     g32 = {k: q.grad.detach().cpu() for k, q in o32.named_parameters()}
+    flipped = []
+    nparams = 0
     for k, p in oracle.named_parameters():
         v = p.grad.float()
         err = (g[k] - v).norm().item()
         err32 = (g32[k] - v).norm().item()
-        assert err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax or err < 2 * err32, \
-            (k, err, err32, v.norm().item())
+        nparams += 1
+        if err / max(v.norm().item(), 1e-12) < gtol or err < 1e-5 * gmax or err < 2 * err32:
+            continue
+        assert fp32_mode == "x6" and err < 1e-4 * gmax, (k, err, err32, v.norm().item(), gmax)
+        flipped.append((k, err / max(v.norm().item(), 1e-12)))
+    assert len(flipped) <= max(8, nparams // 50), flipped      # a handful of parameters of one or two layers, not a trend
     logits_e, _, _ = framework_step(net, x, y, train=False)
     ref_e, _ = oracle_step(oracle, x.double(), y, train=False)
     torch.testing.assert_close(logits_e, ref_e.float(), rtol=5e-3, atol=5e-3)
