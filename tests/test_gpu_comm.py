@@ -170,3 +170,55 @@ def test_rccl_watchdog_diagnoses_a_collective_that_never_finishes(tmp_path):
     assert "aborted by its watchdog" in msg and "collective #3 (all-reduce, bucket 5, 4194304 bytes)" in msg, msg
     assert "transport rccl" in msg and "issued #3, finished #2" in msg, msg
     assert "[dpa comm watchdog]" in r.stderr
+
+
+def _mesh_failure_worker(rank, world, port, out_dir, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    from distributedpytorch_amd.parallel import comm
+    from distributedpytorch_amd.parallel.native_comm import CommError
+    torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream())
+    dev = torch.device("cuda", 0)
+    nc = comm.init_native(rank, world, dev, "127.0.0.1", port, timeout_s=3, rendezvous_timeout_s=60, transport="mesh", exit_grace_s=-1)
+    msg, t0 = "", time.time()
+    try:
+        t = torch.ones(4096, device=dev)
+        nc.allreduce_async(t, 0)                 # collective #1: everyone
+        nc.wait(0)
+        if scenario == "mismatch":
+            t = torch.ones(1000 if rank == 0 else 2000, device=dev)      # the ranks disagree about the bucket size
+            nc.allreduce_async(t, 0)
+            nc.wait(0)
+        elif rank != world - 1:                  # "straggler": the last rank never issues collective #2
+            nc.allreduce_async(t, 0)
+            nc.wait(0)
+        else:
+            time.sleep(8)
+    except CommError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, f"mf{rank}.txt"), "w") as f:
+        f.write(f"{time.time() - t0:.2f}\n{msg}")
+    comm.shutdown(clean=False)
+
+
+def test_mesh_transport_names_the_rank_that_is_behind(tmp_path):
+    """Three ranks on one GPU over the IPC mesh; rank 2 never joins collective #2: ranks 0 and 1 fail inside the 3 s
+    collective timeout with an error that names rank 2 (the transport's stage-counter wait or the front's watchdog,
+    whichever fires first - both name it)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_mesh_failure_worker, nprocs=3, args=(3, 29710, str(tmp_path), "straggler"), join=True)
+    for r in (0, 1):
+        secs, m = open(tmp_path / f"mf{r}.txt").read().split("\n", 1)
+        assert float(secs) < 7.5, secs
+        assert "rank 2" in m and ("timed out" in m or "BEHIND: [2]" in m or "aborted by rank" in m), m
+    msgs = [open(tmp_path / f"mf{r}.txt").read() for r in (0, 1)]
+    assert any("waiting for rank 2" in m or "BEHIND: [2]" in m for m in msgs), msgs
+
+
+def test_mesh_transport_refuses_mismatched_collectives(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_mesh_failure_worker, nprocs=2, args=(2, 29720, str(tmp_path), "mismatch"), join=True)
+    msgs = [open(tmp_path / f"mf{r}.txt").read() for r in range(2)]
+    assert any("collective mismatch with rank" in m for m in msgs), msgs      # nobody adds buffers of different lengths
+    assert all(m.split("\n", 1)[1] for m in msgs), msgs                       # and nobody hangs
