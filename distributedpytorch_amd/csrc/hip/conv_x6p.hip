@@ -178,9 +178,12 @@ DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
 // #10); their code is in the history (commit 6a4c0f5) and their numbers in profiles/: 8 waves / 256-row tiles, one block
 // per CU with 4 row tiles per wave ("tall": 10-15 % slower, r2_x6p_tall_tile.txt), activations pre-split into planes by
 // the producer ("x6pp": 23-30 % slower, r2_x6pp_activation_planes.txt), normalise-on-load (< 1 % net, r2_norm_on_load.txt).
-template <int TN, bool DGRAD, int NW, int MF>
-__global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p) {
-  constexpr int TMW = 2;
+// TMW = 1 ("short" tile, 64 x 64, round 3): for problems whose 128-row tiles would not fill ONE round of the chip's block
+// slots (small batches on 7x7 / 4x4 maps: ResNet-18 layer4 at batch 64 has 200 tiles for 512 slots) - twice the blocks,
+// three resident per CU; each activation fragment still feeds 4 filter fragments x 6 products.
+template <int TN, bool DGRAD, int NW, int MF, int TMW = 2>
+__global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(const ConvParams p) {
+  static_assert(TMW == 1 || TMW == 2, "row tiles per wave");
   constexpr int WROWS = 16 * TMW;                  // rows of the block tile a wave owns
   constexpr int BM = WROWS * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
   constexpr int A_BYTES = BM * 128, BP_BYTES = BN * 64;
@@ -513,17 +516,17 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_x6p_kernel(const ConvParams p
   }
 }
 
-template <int TN, int NW, int MF>
+template <int TN, int NW, int MF, int TMW = 2>
 static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
-  constexpr int BN = TN * 16, BM = 32 * NW;
+  constexpr int BN = TN * 16, BM = 16 * TMW * NW;
   p.tilesM = (p.M - p.m_off + BM - 1) / BM;
   p.tilesN = (p.dC + BN - 1) / BN;
   size_t lds = (size_t)2 * (BM * 128 + 3 * BN * 64);
   const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
-  if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF>), grid, block, lds, s, p);
-  else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF>), grid, block, lds, s, p);
+  if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW>), grid, block, lds, s, p);
+  else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW>), grid, block, lds, s, p);
 }
 
 // Fewest tiles for which the pre-split kernel is taken (DPA_X6P_MIN_TILES, default 96: profiles/r2_x6p_small_batch_sweep.txt).  v >= 0 sets it and returns the
@@ -541,11 +544,13 @@ DPA_API int dpa_x6p_min_tiles(int v) {
 static long long x6p_tiles(const ConvParams& p, bool narrow) {
   return (long long)((p.M + 127) / 128) * ((p.dC + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
 }
-// which: 1 = DPA_X6P_NARROW_BELOW (default 512).  v >= 0 sets the knob and returns the previous value (the kernel tests
-// steer small shapes to each tile width with it); v < 0 only reads it.
+// which: 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_SHORT_BELOW (default 320: problems with fewer 128 x 64 tiles
+// take 64 x 64 tiles; 0 = never.  Measured, profiles/r3_x6p_short_tile.txt: 200-256 tiles +20-30 %, 392 tiles -20 %).  v >= 0 sets the knob and returns the previous value (the kernel tests steer small
+// shapes to each tile shape with it); v < 0 only reads it.
 DPA_API int dpa_x6p_knob(int which, int v) {
-  static int cur[2] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }()};
-  if (which != 1) return -1;
+  static int cur[3] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
+                          [] { const char* e = getenv("DPA_X6P_SHORT_BELOW"); return e ? atoi(e) : 320; }()};
+  if (which < 1 || which > 2) return -1;
   const int prev = cur[which];
   if (v >= 0) cur[which] = v;
   return prev;
@@ -574,7 +579,9 @@ DPA_API int dpa_x6p_plausible(long long M, int dC) {
 // Launches the whole (sub-)problem; returns the number of stats-slab rows it wrote.
 int dpa_x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   p.m_off = 0; p.stats_row0 = 0;
-  if (x6p_narrow(p)) x6p_launch<4, 4, 16>(p, dgrad, s);
-  else               x6p_launch<8, 4, 16>(p, dgrad, s);
+  if (x6p_narrow(p)) {
+    if (x6p_tiles(p, true) < dpa_x6p_knob(2, -1)) x6p_launch<4, 4, 16, 1>(p, dgrad, s);     //  64 x 64
+    else                                          x6p_launch<4, 4, 16>(p, dgrad, s);        // 128 x 64
+  } else                                          x6p_launch<8, 4, 16>(p, dgrad, s);        // 128 x 128
   return p.tilesM;
 }

@@ -9,7 +9,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--only", default="")
-ap.add_argument("--net", default="resnet50", choices=["resnet50", "resnet18_cifar"],
+ap.add_argument("--net", default="resnet50", choices=["resnet50", "resnet18_cifar", "resnet18"],
                 help="resnet18_cifar: BASELINE config 4 (ResNet-18 on 32x32 inputs: 3x3 stem, no max-pool; maps 32/16/8/4)")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -27,6 +27,11 @@ if a.net == "resnet18_cifar":
               (32, 64, 128, 3, 2, 1, 1), (16, 128, 128, 3, 1, 1, 3), (32, 64, 128, 1, 2, 0, 1),
               (16, 128, 256, 3, 2, 1, 1), (8, 256, 256, 3, 1, 1, 3), (16, 128, 256, 1, 2, 0, 1),
               (8, 256, 512, 3, 2, 1, 1), (4, 512, 512, 3, 1, 1, 3), (8, 256, 512, 1, 2, 0, 1)]
+if a.net == "resnet18":          # the reference's default model at 224x224 (SURVEY.md §2.3 shape table)
+    LAYERS = [(224, 8, 64, 7, 2, 3, 1), (56, 64, 64, 3, 1, 1, 4),
+              (56, 64, 128, 3, 2, 1, 1), (28, 128, 128, 3, 1, 1, 3), (56, 64, 128, 1, 2, 0, 1),
+              (28, 128, 256, 3, 2, 1, 1), (14, 256, 256, 3, 1, 1, 3), (28, 128, 256, 1, 2, 0, 1),
+              (14, 256, 512, 3, 2, 1, 1), (7, 512, 512, 3, 1, 1, 3), (14, 256, 512, 1, 2, 0, 1)]
 N = a.batch
 tot = {"fprop": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 def timeit(fn):

@@ -166,16 +166,17 @@ def test_conv_fprop_output_scale_epilogue(shape, dtype, fp32_mode):
     torch.testing.assert_close(y.float(), ref, rtol=rtol, atol=atol * 10)
 
 
-@pytest.fixture(params=["narrow", "wide"])
+@pytest.fixture(params=["short", "narrow", "wide"])
 def x6p_variant(request):
-    """Steer the (small) test problems to each tile width of the pre-split kernel: 128 x 64 and 128 x 128 (two blocks per
-    CU); production picks by problem size (DPA_X6P_NARROW_BELOW)."""
+    """Steer the (small) test problems to each tile shape of the pre-split kernel: 64 x 64 (three blocks per CU), 128 x 64
+    and 128 x 128 (two blocks per CU); production picks by problem size (DPA_X6P_NARROW_BELOW, DPA_X6P_SHORT_BELOW)."""
     from distributedpytorch_amd.ops import native
     lib = native.hip_lib()
-    narrow_below = {"narrow": 1 << 30, "wide": 0}[request.param]
-    prev = lib.dpa_x6p_knob(1, narrow_below)
+    big = 1 << 30
+    narrow_below, short_below = {"short": (big, big), "narrow": (big, 0), "wide": (0, 0)}[request.param]
+    prev = lib.dpa_x6p_knob(1, narrow_below), lib.dpa_x6p_knob(2, short_below)
     yield request.param
-    lib.dpa_x6p_knob(1, prev)
+    lib.dpa_x6p_knob(1, prev[0]); lib.dpa_x6p_knob(2, prev[1])
 
 
 @pytest.mark.parametrize("shape", PRESPLIT_SHAPES)
@@ -201,7 +202,7 @@ def test_conv_presplit_x6_kernel(shape, x6p_variant):
         shift = torch.randn(K, device="cuda", generator=g) * 0.1
         hip_conv.conv_fprop(x, w, y, (s, s), (pd, pd), bias=b, stats=stats, stats_shift=shift, w3=w3)
         rows = hip_conv.last_stats_rows[0]
-        tile_rows = 128
+        tile_rows = 64 if x6p_variant == "short" else 128
         assert rows == (M + tile_rows - 1) // tile_rows     # one slab row per M-tile of that variant: the pre-split kernel ran
         yr = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=s, padding=pd).permute(0, 2, 3, 1)
         rtol, atol = _tol(torch.float32, k * k * C)

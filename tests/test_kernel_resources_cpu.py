@@ -57,9 +57,10 @@ def test_presplit_kernels_keep_their_residency_without_scratch(tmp_path):
     """conv_x6p.hip: every instantiation of the production tile (two blocks per CU: <= 256 registers) and of the narrow
     tile fits two waves per SIMD with no scratch."""
     res = {k: v for k, v in _resources(os.path.join(HIP_DIR, "conv_x6p.hip"), tmp_path).items() if "conv_x6p_kernel" in k}
-    assert len(res) == 4, f"expected the four production instantiations of conv_x6p_kernel, found {len(res)}"
+    assert len(res) == 6, f"expected the six production instantiations of conv_x6p_kernel, found {len(res)}"
     bad = {}
     for k, v in res.items():
-        if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < 2:
+        short = k.endswith("Li1EEv10ConvParams")           # the 64 x 64 tile is built for three blocks per CU
+        if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < (3 if short else 2):
             bad[k] = v
     assert not bad, "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
