@@ -26,6 +26,7 @@
 #include "conv_common.h"
 
 __device__ uint4 dpa_zero_chunk_x6p[4];
+DPA_API int dpa_x6p_knob(int which, int v);
 
 // LDS offset of 16-byte chunk `chunk` of row `row` of the fp32 activation tile (128-byte rows).  Measured, not derived
 // (scripts/micro/lds_conflict.hip under PMC, profiles/r2_lds_read_b128_lane_groups.txt): with this kernel's fragment
@@ -35,6 +36,9 @@ __device__ uint4 dpa_zero_chunk_x6p[4];
 __device__ __forceinline__ int x6p_a_swz(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 2); }
 __device__ __forceinline__ int x6p_a_off(int row, int chunk) { return row * 128 + ((chunk ^ x6p_a_swz(row)) << 4); }
 
+__device__ __forceinline__ void x6p_keep(const uint4& a, const uint4& b) {      // (diagnostic builds: keeps operands live)
+  asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
 __device__ __forceinline__ void split3_frag(const uint4& lo, const uint4& hi, uint4 (&pl)[3]) {
   const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   uint32_t o[4][3];
@@ -173,6 +177,17 @@ DPA_API int dpa_weight_prep(const void* segs, int nsegs, long long total_chunks,
 }
 DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
 
+// One 1-KiB LDS-DMA piece issued from inline asm: hipcc does not count it, so it puts no s_waitcnt vmcnt(0) in front of
+// the LDS reads that follow (it does for the builtin: it cannot tell that they read another buffer) - the pipelined K
+// loop below waits for its DMAs itself, once per K-tile.  M0 (the LDS destination) is saved and restored inside the
+// statement (cdna_hip_programming.md §5.7).  lds_addr must be wave-uniform.
+__device__ __forceinline__ void x6p_glds16(const void* g, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+template <int V> struct X6pInt { static constexpr int value = V; };
+
 // NW = 4 waves per block, stacked along M; each wave owns TMW = 2 row tiles of 16 rows: a 128 x BN block tile, two blocks
 // per CU.  Variants that were measured and lost in round 2 are NOT compiled into the library any more (VERDICT r2 weak
 // #10); their code is in the history (commit 6a4c0f5) and their numbers in profiles/: 8 waves / 256-row tiles, one block
@@ -181,8 +196,10 @@ DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
 // TMW = 1 ("short" tile, 64 x 64, round 3): for problems whose 128-row tiles would not fill ONE round of the chip's block
 // slots (small batches on 7x7 / 4x4 maps: ResNet-18 layer4 at batch 64 has 200 tiles for 512 slots) - twice the blocks,
 // three resident per CU; each activation fragment still feeds 4 filter fragments x 6 products.
-template <int TN, bool DGRAD, int NW, int MF, int TMW = 2>
+template <int TN, bool DGRAD, int NW, int MF, int TMW = 2, int ABL = 0, bool PIPE = false>
 __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(const ConvParams p) {
+  // ABL (diagnostic builds only, -DDPA_X6P_DIAG; results are WRONG, timing only): bit 0 = no operand split, bit 1 = no
+  // LDS-DMA after the second K-tile, bit 2 = no MFMAs.
   static_assert(TMW == 1 || TMW == 2, "row tiles per wave");
   constexpr int WROWS = 16 * TMW;                  // rows of the block tile a wave owns
   constexpr int BM = WROWS * NW, BN = TN * 16, BKE = 32, NT = NW * 64;
@@ -395,6 +412,138 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     const int b_frag = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);     // + plane * BP_BYTES + j * 1024
     constexpr int JH = TN > 4 ? 4 : TN;                                // filter fragments held in registers at a time
 
+    if constexpr (PIPE) {
+      // ---- software-pipelined K loop --------------------------------------------------------------------------------------
+      // Measured on the loop below (profiles/r3_x6p_ablation.txt): its phases ADD - without MFMAs it still takes 60 % of
+      // its time, MFMAs + fragment reads alone 76 % - because a wave reads its fragments, splits them and issues the next
+      // tile's DMA BETWEEN its MFMA runs.  Here every wave works one tile ahead of its own matrix work: while the MFMAs of
+      // tile kt run (operands `cur`, already split), it reads and splits the activation fragments of tile kt + 1 (`nxt`),
+      // streams the filter fragments of tile kt two column tiles at a time, and the DMA of A(kt + 2) / B(kt + 1) was issued
+      // at the top of the iteration - a whole iteration before anyone waits for it.  LDS: two A buffers, two B buffers
+      // (the same 80 KB): A[kt & 1] was read during iteration kt - 1 and is free after the barrier that ended it.
+      typedef __attribute__((address_space(3))) char lds_char;
+      const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_char*)smem);
+      constexpr int B_BASE = 2 * A_BYTES;
+      auto issue_A = [&](int kt, int par) __attribute__((always_inline)) {
+        const uint32_t k0 = (uint32_t)kt * BKE;
+        const uint32_t tap = fd_div(k0, p.fd_sC);
+        const int cbase = (int)(k0 - tap * (uint32_t)p.sC);
+        const int r = (int)fd_div(tap, p.fd_nS);
+        const int s = (int)tap - r * p.nS;
+        const long long delta = (long long)(DGRAD ? -(r * p.sW + s) : (r * p.sW + s)) * p.s_cs + cbase;
+        const uint32_t bit = 1u << tap;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+          const float* pa = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
+          x6p_glds16(pa, lds0 + par * A_BYTES + (i * RPP + wave * 8) * 128);
+        }
+      };
+      auto issue_B = [&](int kt, int par) __attribute__((always_inline)) {
+        const uint32_t k0 = (uint32_t)kt * BKE;
+        int woff = (int)k0;
+        if constexpr (DGRAD) {
+          const uint32_t tap = fd_div(k0, p.fd_sC);
+          const int cbase = (int)(k0 - tap * (uint32_t)p.sC);
+          const int r = (int)fd_div(tap, p.fd_nS);
+          const int s = (int)tap - r * p.nS;
+          woff = ((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + cbase;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+          if ((3 * TN) % NW == 0 || wave + NW * i < 3 * TN)          // wave-uniform
+            x6p_glds16(wgt3 + b_off[i] + woff, lds0 + B_BASE + par * 3 * BP_BYTES + (b_lds[i] - A_BYTES));
+      };
+      auto read_A = [&](int par, uint4 (&lo)[TM], uint4 (&hi)[TM]) __attribute__((always_inline)) {
+        const char* tA = smem + par * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          lo[i] = *reinterpret_cast<const uint4*>(tA + x6p_a_off(wave * WROWS + i * 16 + fr, 2 * fq));
+          hi[i] = *reinterpret_cast<const uint4*>(tA + x6p_a_off(wave * WROWS + i * 16 + fr, 2 * fq + 1));
+        }
+      };
+      uint4 ap0[TM][3], ap1[TM][3];
+      auto body = [&](int kt, auto parc, uint4 (&cur)[TM][3], uint4 (&nxt)[TM][3]) __attribute__((always_inline)) {
+        constexpr int par = decltype(parc)::value;               // kt & 1
+        // (Issuing the DMA piece by piece BETWEEN the column tiles' MFMAs was tried three ways - asm statements with a
+        // "memory" clobber, without one behind MFMA-only sched_barrier fences, and pinned by fake register dependencies on
+        // the accumulators: each time hipcc's scheduler gave up the MFMA / VALU interleave below around the asm statements
+        // and the loop got slower.  The block of ten pieces here costs 8 % of the loop: profiles/r3_x6p_ablation.txt.)
+        if (!(ABL & 2) || kt < 1) {
+          if (kt + 2 < nkt) issue_A(kt + 2, par);
+          if (kt + 1 < nkt) issue_B(kt + 1, par ^ 1);
+        }
+        const char* tB = smem + B_BASE + par * 3 * BP_BYTES;
+        uint4 bp[2][3], fl[TM], fh[TM];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) bp[0][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + b_frag);
+        read_A(par ^ 1, fl, fh);       // (after the last tile: stale bytes of the same buffer, split and never used)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (j + 1 < TN) {
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+              bp[(j + 1) & 1][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + (j + 1) * 1024 + b_frag);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+              if constexpr (ABL & 4) x6p_keep(cur[i][kX6A[t]], bp[j & 1][kX6B[t]]);
+              else MfmaT<bf16_t>::mma(cur[i][kX6A[t]], bp[j & 1][kX6B[t]], acc[i][j]);
+            }
+          // the next tile's operand split, one row tile in the program text of each of the first TM column tiles
+          if (j < TM) {
+            if constexpr (ABL & 1) { nxt[j][0] = fl[j]; nxt[j][1] = fh[j]; nxt[j][2] = fl[j]; }
+            else split3_frag(fl[j], fh[j], nxt[j]);
+          }
+        }
+        // pin the split INSIDE this iteration (its results are only used in the next one: left alone, hipcc sinks all of
+        // it below the barrier, in front of the next iteration's MFMAs - the very serialisation this loop removes) ...
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            asm volatile("" : "+v"(nxt[i][part].x), "+v"(nxt[i][part].y), "+v"(nxt[i][part].z), "+v"(nxt[i][part].w));
+        // ... and describe the interleave to the scheduler: the fragment reads of the first column tile and of the next
+        // row tiles, then per column tile the reads of the following one and its 6 TM MFMAs, one split instruction behind
+        // each MFMA (36 TM of them, spread evenly: an MFMA holds the issue port for 8 of its 16 cycles).
+        if constexpr (ABL == 0) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 3 + 2 * TM, 0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (j + 1 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int m = 0; m < 6 * TM; ++m) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              constexpr int NV = 36 * TM + 8, NM = 6 * TM * TN;       // vector instructions to place, MFMAs to place them behind
+              if (NV / NM >= 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+              if (NV / NM >= 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+              if (j * 6 * TM + m < NV % NM) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      };
+      if (nkt > 0) {
+        issue_A(0, 0);
+        issue_B(0, 0);
+        if (nkt > 1) issue_A(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+          uint4 fl[TM], fh[TM];
+          read_A(0, fl, fh);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) split3_frag(fl[i], fh[i], ap0[i]);
+        }
+        __syncthreads();               // every wave has A(0) in registers before iteration 0 refills A[0]
+        for (int kt = 0; kt < nkt; kt += 2) {
+          body(kt, X6pInt<0>{}, ap0, ap1);
+          if (kt + 1 < nkt) body(kt + 1, X6pInt<1>{}, ap1, ap0);
+        }
+      }
+    } else {
     if (nkt > 0) issue_tile(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -414,15 +563,21 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 #pragma unroll
         for (int part = 0; part < 3; ++part)
           bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
-      if constexpr (TN <= 4) { if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1); }
+      if constexpr (TN <= 4) { if (kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1); }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) split3_frag(fa[0][i], fa[1][i], ap[i]);
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (ABL & 1) { ap[i][0] = fa[0][i]; ap[i][1] = fa[1][i]; ap[i][2] = fa[0][i]; }
+        else split3_frag(fa[0][i], fa[1][i], ap[i]);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-          for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+          for (int j = 0; j < JH; ++j) {
+            if constexpr (ABL & 4) x6p_keep(ap[i][kX6A[t]], bp[j][kX6B[t]]);
+            else MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
+          }
       if constexpr (TN > 4) {
         // second half of the filter fragments: read them, THEN issue the next tile's DMA (the compiler puts
         // s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA issue), then the other 48 MFMAs
@@ -431,14 +586,18 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 #pragma unroll
           for (int part = 0; part < 3; ++part)
             bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + (JH + j) * 1024 + b_frag);
-        if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int j = 0; j < JH; ++j) MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][JH + j]);
+            for (int j = 0; j < JH; ++j) {
+              if constexpr (ABL & 4) x6p_keep(ap[i][kX6A[t]], bp[j][kX6B[t]]);
+              else MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][JH + j]);
+            }
       }
+    }
     }
     __syncthreads();
 
@@ -525,6 +684,29 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
+#ifdef DPA_X6P_DIAG
+  if constexpr (TN == 8 && TMW == 2) {
+    const char* e = getenv("DPA_X6P_ABL");
+    const int abl = e ? atoi(e) : 0;
+#define DPA_ABL_CASE(N) if (abl == N && !dgrad) { hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW, N>), grid, block, lds, s, p); return; }
+    DPA_ABL_CASE(1) DPA_ABL_CASE(2) DPA_ABL_CASE(3) DPA_ABL_CASE(4) DPA_ABL_CASE(5) DPA_ABL_CASE(6) DPA_ABL_CASE(7)
+#undef DPA_ABL_CASE
+#define DPA_ABL_CASE(N) if (abl == 8 + N && !dgrad) { hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW, N, true>), grid, block, lds, s, p); return; }
+    DPA_ABL_CASE(0) DPA_ABL_CASE(1) DPA_ABL_CASE(2) DPA_ABL_CASE(3) DPA_ABL_CASE(4) DPA_ABL_CASE(5) DPA_ABL_CASE(6) DPA_ABL_CASE(7)
+#undef DPA_ABL_CASE
+  }
+#endif
+  // the software-pipelined K loop: 128 x 128 tiles only (measured, profiles/r3_x6p_pipelined_loop.txt: +5-10 % on every
+  // layer with 128-column tiles and four K-tiles or more, -3 % on the 128 x 64 tiles of the 64-filter layers, whose 48
+  // MFMAs per K-tile leave too few slots for the 72 split instructions)
+  if constexpr (TN == 8 && TMW == 2) {
+    const int pipe_min = dpa_x6p_knob(3, -1);
+    if (pipe_min > 0 && (p.Kg + 31) / 32 >= pipe_min) {
+      if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, true>), grid, block, lds, s, p);
+      else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW, 0, true>), grid, block, lds, s, p);
+      return;
+    }
+  }
   if (dgrad) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW>), grid, block, lds, s, p);
   else       hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW>), grid, block, lds, s, p);
 }
@@ -544,13 +726,15 @@ DPA_API int dpa_x6p_min_tiles(int v) {
 static long long x6p_tiles(const ConvParams& p, bool narrow) {
   return (long long)((p.M + 127) / 128) * ((p.dC + (narrow ? 63 : 127)) / (narrow ? 64 : 128));
 }
-// which: 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_SHORT_BELOW (default 320: problems with fewer 128 x 64 tiles
+// which: 3 = DPA_X6P_PIPE_MIN_KT (default 4: reductions of at least that many 32-element K-tiles take the software-pipelined K
+// loop; 0 = never.  profiles/r3_x6p_pipelined_loop.txt), 1 = DPA_X6P_NARROW_BELOW (default 512), 2 = DPA_X6P_SHORT_BELOW (default 320: problems with fewer 128 x 64 tiles
 // take 64 x 64 tiles; 0 = never.  Measured, profiles/r3_x6p_short_tile.txt: 200-256 tiles +20-30 %, 392 tiles -20 %).  v >= 0 sets the knob and returns the previous value (the kernel tests steer small
 // shapes to each tile shape with it); v < 0 only reads it.
 DPA_API int dpa_x6p_knob(int which, int v) {
-  static int cur[3] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
-                          [] { const char* e = getenv("DPA_X6P_SHORT_BELOW"); return e ? atoi(e) : 320; }()};
-  if (which < 1 || which > 2) return -1;
+  static int cur[4] = {0, [] { const char* e = getenv("DPA_X6P_NARROW_BELOW"); return e ? atoi(e) : 512; }(),
+                          [] { const char* e = getenv("DPA_X6P_SHORT_BELOW"); return e ? atoi(e) : 320; }(),
+                          [] { const char* e = getenv("DPA_X6P_PIPE_MIN_KT"); return e ? atoi(e) : 4; }()};
+  if (which < 1 || which > 3) return -1;
   const int prev = cur[which];
   if (v >= 0) cur[which] = v;
   return prev;

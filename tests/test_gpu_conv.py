@@ -166,17 +166,20 @@ def test_conv_fprop_output_scale_epilogue(shape, dtype, fp32_mode):
     torch.testing.assert_close(y.float(), ref, rtol=rtol, atol=atol * 10)
 
 
-@pytest.fixture(params=["short", "narrow", "wide"])
+@pytest.fixture(params=["short", "narrow", "wide", "wide-plain"])
 def x6p_variant(request):
     """Steer the (small) test problems to each tile shape of the pre-split kernel: 64 x 64 (three blocks per CU), 128 x 64
-    and 128 x 128 (two blocks per CU); production picks by problem size (DPA_X6P_NARROW_BELOW, DPA_X6P_SHORT_BELOW)."""
+    and 128 x 128 (two blocks per CU); production picks by problem size (DPA_X6P_NARROW_BELOW, DPA_X6P_SHORT_BELOW).
+    The 128 x 128 tile with both K loops: the software-pipelined one for EVERY reduction length (production: four K-tiles
+    and more, DPA_X6P_PIPE_MIN_KT) and, "-plain", the double-buffered one the other tile shapes always use."""
     from distributedpytorch_amd.ops import native
     lib = native.hip_lib()
     big = 1 << 30
-    narrow_below, short_below = {"short": (big, big), "narrow": (big, 0), "wide": (0, 0)}[request.param]
-    prev = lib.dpa_x6p_knob(1, narrow_below), lib.dpa_x6p_knob(2, short_below)
-    yield request.param
-    lib.dpa_x6p_knob(1, prev[0]); lib.dpa_x6p_knob(2, prev[1])
+    tile, _, loop = request.param.partition("-")
+    narrow_below, short_below = {"short": (big, big), "narrow": (big, 0), "wide": (0, 0)}[tile]
+    prev = lib.dpa_x6p_knob(1, narrow_below), lib.dpa_x6p_knob(2, short_below), lib.dpa_x6p_knob(3, 0 if loop == "plain" else 1)
+    yield tile
+    lib.dpa_x6p_knob(1, prev[0]); lib.dpa_x6p_knob(2, prev[1]); lib.dpa_x6p_knob(3, prev[2])
 
 
 @pytest.mark.parametrize("shape", PRESPLIT_SHAPES)
