@@ -55,7 +55,9 @@ struct TrTile {
 // Resident blocks per CU the register budget is set for: 3, or 2 for x6 (plane splits) and for the bf16 64 x 256 tile (at
 // 3 it spilled 26 VGPRs to scratch: stem wgrad -24 %, 56x56 256->64 -9 % at 2).
 #define WG_MINB(T, WN, TN, X6) ((X6 || (sizeof(T) == 2 && WN == 4 && TN == 4)) ? 2 : 3)
-template <typename T, int WM, int WN, int TM, int TN, bool X6 = false>
+// ABL (diagnostic builds only, -DDPA_WG_DIAG; results are WRONG, timing only): bit 0 = no operand split, bit 1 = no global
+// loads after the first tile, bit 2 = no MFMAs, bit 3 = no LDS stores after the first tile.
+template <typename T, int WM, int WN, int TM, int TN, bool X6 = false, int ABL = 0>
 __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel(const WgradParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);
@@ -154,8 +156,11 @@ __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel
 #pragma unroll
       for (int i = 0; i < A_PASSES; ++i) {
         uint32_t lo[3], hi[3];
+        if constexpr (ABL & 1) { lo[0] = ra[i].x; lo[1] = ra[i].y; lo[2] = ra[i].x; hi[0] = ra[i].z; hi[1] = ra[i].w; hi[2] = ra[i].z; }
+        else {
         split3_pair(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), lo);
         split3_pair(__uint_as_float(ra[i].z), __uint_as_float(ra[i].w), hi);
+        }
 #pragma unroll
         for (int part = 0; part < 3; ++part)
           *reinterpret_cast<uint2*>(ldsA + part * PLANE_A + TA::off(ra0 + RPP_A * i, ca * 8)) = make_uint2(lo[part], hi[part]);
@@ -163,8 +168,11 @@ __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel
 #pragma unroll
       for (int i = 0; i < B_CHUNKS; ++i) {
         uint32_t lo[3], hi[3];
+        if constexpr (ABL & 1) { lo[0] = rb[i].x; lo[1] = rb[i].y; lo[2] = rb[i].x; hi[0] = rb[i].z; hi[1] = rb[i].w; hi[2] = rb[i].z; }
+        else {
         split3_pair(__uint_as_float(rb[i].x), __uint_as_float(rb[i].y), lo);
         split3_pair(__uint_as_float(rb[i].z), __uint_as_float(rb[i].w), hi);
+        }
 #pragma unroll
         for (int part = 0; part < 3; ++part)
           *reinterpret_cast<uint2*>(ldsB + part * PLANE_B + TB::off(brow, (bsub + TPR * i) * 8)) = make_uint2(lo[part], hi[part]);
@@ -192,7 +200,7 @@ __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel
     __syncthreads();
     for (int pix0 = pix_begin; pix0 < pix_end; pix0 += BKP) {
       const bool more = pix0 + BKP < pix_end;
-      if (more) load_tile(pix0 + BKP);
+      if (more && !(ABL & 2)) load_tile(pix0 + BKP);
       if constexpr (X6) {
         // one 32-pixel k-step per tile; the planes are bf16 tiles, read with the same transposed loads as the bf16 path
         typedef __attribute__((address_space(3))) bf16x4 lds_b4;
@@ -223,8 +231,10 @@ __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel
 #pragma unroll
           for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kX6A[t]], fb[j][kX6B[t]], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              if constexpr (ABL & 4) asm volatile("" :: "v"(fa[kX6A[t]]), "v"(fb[j][kX6B[t]]));
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kX6A[t]], fb[j][kX6B[t]], acc[i][j], 0, 0, 0);
+            }
         }
       } else if constexpr (sizeof(T) == 2) {
         // bf16: per 32-pixel k-step, lane needs k = 8*fq + j (j = 0..7) of column fr: two transposed
@@ -276,7 +286,7 @@ __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel
       }
       __syncthreads();
       if (more) {
-        store_tile();
+        if constexpr (!(ABL & 8)) store_tile();
         __syncthreads();
       }
     }
@@ -292,6 +302,254 @@ __global__ void __launch_bounds__(256, WG_MINB(T, WN, TN, X6)) conv_wgrad_kernel
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = m0 + wm * TM * 16 + i * 16 + fq * 4 + e;
+        if (row < p.K && col < p.Ng) {
+          float* o = out + (size_t)row * p.Ng + col;
+          *o = (p.accumulate && p.splitK == 1) ? (*o + acc[i][j][e]) : acc[i][j][e];
+        }
+      }
+    }
+}
+
+__device__ uint4 dpa_zero_chunk_wg[1];
+
+// ---- fp32 (x6) weight gradient, second structure ("x6q"): 8 waves, ONE block per CU, plane tiles double-buffered in LDS,
+// ONE barrier per K-tile, staging interleaved with the matrix work --------------------------------------------------------
+// Measured on the kernel above (profiles/r3_wgrad_ablation.txt, 14x14 256->256 3x3): its phases ADD - without the global
+// loads it takes 75 % of its time, without the split + LDS stores 63 %, without MFMAs 60 %: MFMA phase, barrier, store
+// phase, barrier, and the matrix pipe idles through every store phase (50 % busy).  Here the registers of a thread hold
+// tile t + 1 (loaded during iteration t - 1) while the MFMAs of tile t run; their split and LDS stores go into the OTHER
+// stage buffer between those MFMAs (every wave does both: two waves per SIMD, like two blocks of the kernel above), and the
+// global loads of tile t + 2 are issued at the top of the iteration into the second register set.
+// Tiles: 256 x 128 (WM = 4, WN = 2) or 128 x 256 (WM = 2, WN = 4), 64 x 64 per wave: per MFMA 25 % fewer split
+// instructions and LDS-store bytes than the 128 x 128 tile.  LDS: 2 x 72 KB.
+// (The same kernel on v_mfma_f32_32x32x16_bf16 - half the matrix instructions, three times the free issue slots - ran
+// 13 % fewer cycles at a 13 % lower clock, i.e. the same wall time: profiles/r3_wgrad_x6q.txt.  Not kept.)
+template <int WM, int WN>
+__global__ void __launch_bounds__(512, 2) conv_wgrad_x6q_kernel(const WgradParams p) {
+  static_assert(WM * WN == 8, "8 waves per block");
+  constexpr int TM = 4, TN = 4, NT = 512, BKP = 32;
+  constexpr int BM = WM * 64, BN = WN * 64;
+  typedef TrTile<BM * 2> TA;
+  typedef TrTile<BN * 2> TB;
+  static_assert(TA::SWZ && TB::SWZ, "swizzled plane tiles");
+  constexpr int PLANE_A = BKP * TA::PITCH, PLANE_B = BKP * TB::PITCH;
+  constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
+  constexpr int CPR_A = BM / 4, CPR_B = BN / 4;        // 16-byte (4 x fp32) chunks per pixel row
+  constexpr int A_PASSES = BKP * CPR_A / NT;           // 4 (BM = 256) or 2 (BM = 128)
+  constexpr int RPP_A = NT / CPR_A;                    // pixel rows per pass (A)
+  constexpr int TPR = NT / BKP;                        // 16 threads per pixel row (B)
+  constexpr int B_CHUNKS = CPR_B / TPR;                // 2 (BN = 128) or 4 (BN = 256)
+  constexpr int ITEMS = A_PASSES + B_CHUNKS;           // 16-byte chunks a thread stages per K-tile (6)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int bid = p.xcd_order ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tilesMN = p.tilesM * p.tilesN;
+  const int z = bid / tilesMN;
+  bid -= z * tilesMN;
+  const int tm = bid / p.tilesN, tn = bid - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int pix_begin = z * p.pixPerSplit;
+  const int pix_end = min(p.P, pix_begin + p.pixPerSplit);
+  const float* __restrict__ dy = reinterpret_cast<const float*>(p.dy);
+  const float* __restrict__ x = reinterpret_cast<const float*>(p.x);
+
+  const int ca = tid % CPR_A, ra0 = tid / CPR_A;
+  const int a_col = m0 + ca * 4;
+  const bool a_ok = a_col < p.K;
+  const int brow = tid / TPR, bsub = tid % TPR;
+  int b_dr[B_CHUNKS], b_ds[B_CHUNKS], b_delta[B_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < B_CHUNKS; ++i) {
+    const int nidx = n0 + (bsub + TPR * i) * 4;
+    if (nidx < p.Ng) {
+      const uint32_t tap = fd_div((uint32_t)nidx, p.fd_C);
+      const int c = nidx - (int)tap * p.C;
+      const int r = (int)fd_div(tap, p.fd_S);
+      const int s = (int)tap - r * p.S;
+      b_dr[i] = r; b_ds[i] = s;
+      b_delta[i] = (r * p.W + s) * p.c_cs + p.c_co + c;
+    } else {
+      b_dr[i] = -0x40000000; b_ds[i] = 0; b_delta[i] = 0;     // fails the bounds check below -> zeros
+    }
+  }
+
+  // tile at pix0 -> registers (zeros beyond pix_end / outside the image / beyond K, Ng).  UNCONDITIONAL loads through an
+  // address select (the zero chunk for everything masked): a load under a branch makes hipcc wait vmcnt(0) where the
+  // registers of the OTHER set are consumed, i.e. for the loads just issued (cdna_hip_programming.md §5, trap (c)).
+  // In four parts, so that an iteration can spread them over its first MFMA segments.
+  const float* const zero = reinterpret_cast<const float*>(dpa_zero_chunk_wg);
+  struct BRow { const float* base; int h0, w0; bool pin; };
+  auto load_A = [&](int pix0, uint4 (&r)[ITEMS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int pix = pix0 + ra0 + RPP_A * i;
+      const float* ptr = (a_ok && pix < pix_end) ? dy + ((size_t)pix * p.k_cs + p.k_co + a_col) : zero;
+      r[i] = *reinterpret_cast<const uint4*>(ptr);
+    }
+  };
+  auto decompose_B = [&](int pix0) __attribute__((always_inline)) {
+    BRow b;
+    const int pix = pix0 + brow;
+    b.pin = pix < pix_end;
+    const uint32_t t1 = fd_div((uint32_t)(b.pin ? pix : 0), p.fd_Wo);
+    const int wo = (b.pin ? pix : 0) - (int)t1 * p.Wo;
+    const uint32_t img = fd_div(t1, p.fd_Ho);
+    const int ho = (int)t1 - (int)img * p.Ho;
+    b.h0 = ho * p.sh - p.ph; b.w0 = wo * p.sw - p.pw;
+    b.base = x + ((size_t)img * (p.H * p.W) + (ptrdiff_t)(b.h0 * p.W + b.w0)) * p.c_cs;
+    return b;
+  };
+  auto load_B = [&](const BRow& b, int i0, int i1, uint4 (&r)[ITEMS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const bool ok = b.pin && (unsigned)(b.h0 + b_dr[i]) < (unsigned)p.H && (unsigned)(b.w0 + b_ds[i]) < (unsigned)p.W;
+      const float* ptr = ok ? b.base + b_delta[i] : zero;
+      r[A_PASSES + i] = *reinterpret_cast<const uint4*>(ptr);
+    }
+  };
+  auto load_tile = [&](int pix0, uint4 (&r)[ITEMS]) __attribute__((always_inline)) {
+    load_A(pix0, r);
+    const BRow b = decompose_B(pix0);
+    load_B(b, 0, B_CHUNKS, r);
+  };
+  // one staged chunk (4 fp32) -> three bf16 planes in the stage buffer, in two halves (one split3_pair each) + the stores
+  auto store_item = [&](int it, const uint32_t (&lo)[3], const uint32_t (&hi)[3], char* stage) __attribute__((always_inline)) {
+    if (it < A_PASSES) {
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        *reinterpret_cast<uint2*>(stage + part * PLANE_A + TA::off(ra0 + RPP_A * it, ca * 8)) = make_uint2(lo[part], hi[part]);
+    } else {
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        *reinterpret_cast<uint2*>(stage + 3 * PLANE_A + part * PLANE_B + TB::off(brow, (bsub + TPR * (it - A_PASSES)) * 8)) =
+            make_uint2(lo[part], hi[part]);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+  const int q = fr >> 2, pp = fr & 3;
+  const int krow = 8 * fq + q;
+  auto read_fa = [&](const char* ldsA, int i, bf16x8 (&fa)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      const char* pl = ldsA + part * PLANE_A;
+      const int cb = (wm * 64 + i * 16 + 4 * pp) * 2;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TA::off(krow, cb)));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TA::off(krow + 4, cb)));
+      fa[part] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  // Iteration t.  MFMAs of the tile in `cur` in 16 segments of 6 (row tile i, quarter s), each fenced off from the next
+  // (sched_barrier(0): hipcc's scheduler, left the whole iteration, clusters 60 MFMAs and 100 vector instructions) and each
+  // with its own share of the other work, interleaved inside the segment by sched_group_barrier:
+  //   row tile 0: the global loads of tile t + 2 into `rl` (addresses in the first three segments, B loads in the last two);
+  //   row tiles 1-3: split + LDS stores of `rs` (tile t + 1, loaded a whole iteration ago) into `nxt`: one split3_pair per
+  //                  segment, the three 8-byte stores of a chunk behind its second pair;
+  //   segment 1 of every row tile: the fragment reads of the next row tile.
+  // One barrier at the end.
+  auto iteration = [&](int pix_next2, const char* cur, char* nxt, uint4 (&rl)[ITEMS], uint4 (&rs)[ITEMS]) __attribute__((always_inline)) {
+    const char* ldsA = cur;
+    const char* ldsB = cur + 3 * PLANE_A;
+    bf16x8 fb[TN][3], fa[2][3];
+    read_fa(ldsA, 0, fa[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        const char* pl = ldsB + part * PLANE_B;
+        const int cb = (wn * 64 + j * 16 + 4 * pp) * 2;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TB::off(krow, cb)));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(pl + TB::off(krow + 4, cb)));
+        fb[j][part] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    BRow brw;
+    uint32_t lo3[3], hi3[3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        int nread = 0, nvalu = 0, nwrite = 0, nvmem = 0;
+        if (sg == 1 && i + 1 < TM) { read_fa(ldsA, i + 1, fa[(i + 1) & 1]); nread = 6; }
+#pragma unroll
+        for (int m = 6 * sg; m < 6 * sg + 6; ++m) {
+          const int t = m / TN, j = m % TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][kX6A[t]], fb[j][kX6B[t]], acc[i][j], 0, 0, 0);
+        }
+        if (i == 0) {
+          if (sg == 0) { load_A(pix_next2, rl); nvalu = 6 * A_PASSES; nvmem = A_PASSES; }
+          if (sg == 1) { brw = decompose_B(pix_next2); nvalu = 24; }
+          if (sg == 2) { load_B(brw, 0, B_CHUNKS / 2, rl); nvalu = 5 * B_CHUNKS; nvmem = B_CHUNKS / 2; }
+          if (sg == 3) { load_B(brw, B_CHUNKS / 2, B_CHUNKS, rl); nvalu = 5 * B_CHUNKS; nvmem = B_CHUNKS / 2; }
+        } else {
+          const int pair = (i - 1) * 4 + sg;          // 0 .. 11: chunk pair / 2, half pair & 1
+          const int it = pair >> 1;
+          if ((pair & 1) == 0) split3_pair(__uint_as_float(rs[it].x), __uint_as_float(rs[it].y), lo3);
+          else {
+            split3_pair(__uint_as_float(rs[it].z), __uint_as_float(rs[it].w), hi3);
+            store_item(it, lo3, hi3, nxt);
+            nwrite = 3;
+          }
+          nvalu = 10;
+        }
+        // the segment's interleave: fragment reads first, then vector instructions spread behind the six MFMAs (an MFMA
+        // holds the issue port for 8 of its 16 cycles), loads / LDS stores in the second half
+        if (nread) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          if (m == 1 && nvalu > 12) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          if (m == 3 && nvalu > 16) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          if (m >= 3 && nwrite) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (m >= 6 - nvmem && nvmem) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  };
+
+  if (pix_begin < pix_end) {
+    uint4 r0[ITEMS], r1[ITEMS];
+    char* buf0 = smem;
+    char* buf1 = smem + STAGE;
+    load_tile(pix_begin, r0);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      uint32_t lo[3], hi[3];
+      split3_pair(__uint_as_float(r0[it].x), __uint_as_float(r0[it].y), lo);
+      split3_pair(__uint_as_float(r0[it].z), __uint_as_float(r0[it].w), hi);
+      store_item(it, lo, hi, buf0);
+    }
+    load_tile(pix_begin + BKP, r1);
+    __syncthreads();
+    // (tiles beyond pix_end load as zeros and are staged like any other - no branch inside an iteration; the last
+    // iteration's stores go into a buffer nobody reads any more)
+    for (int pix0 = pix_begin; pix0 < pix_end; pix0 += 2 * BKP) {
+      iteration(pix0 + 2 * BKP, buf0, buf1, r0, r1);
+      if (pix0 + BKP < pix_end) iteration(pix0 + 3 * BKP, buf1, buf0, r1, r0);
+    }
+  }
+
+  float* out = p.out + (size_t)z * p.K * p.Ng;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + wm * 64 + i * 16 + fq * 4 + e;
         if (row < p.K && col < p.Ng) {
           float* o = out + (size_t)row * p.Ng + col;
           *o = (p.accumulate && p.splitK == 1) ? (*o + acc[i][j][e]) : acc[i][j][e];
@@ -357,7 +615,19 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   if (x6) {
     if constexpr (sizeof(T) == 4) {
       const size_t lds = (size_t)BKP * 3 * (TrTile<BM * 2>::PITCH + TrTile<BN * 2>::PITCH);
+#ifdef DPA_WG_DIAG
+      if constexpr (WM == 2 && WN == 2 && TM == 4 && TN == 4) {
+        const char* e = getenv("DPA_WG_ABL");
+        const int abl = e ? atoi(e) : 0;
+#define DPA_ABL_CASE(N) if (abl == N) { hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN, true, N>), dim3(tiles * split), dim3(256), lds, s, p); goto launched; }
+        DPA_ABL_CASE(1) DPA_ABL_CASE(2) DPA_ABL_CASE(3) DPA_ABL_CASE(4) DPA_ABL_CASE(8) DPA_ABL_CASE(9) DPA_ABL_CASE(12) DPA_ABL_CASE(14) DPA_ABL_CASE(15)
+#undef DPA_ABL_CASE
+      }
+#endif
       hipLaunchKernelGGL((conv_wgrad_kernel<T, WM, WN, TM, TN, true>), dim3(tiles * split), dim3(256), lds, s, p);
+#ifdef DPA_WG_DIAG
+      launched:;
+#endif
     }
   } else {
     const size_t lds = (sizeof(T) == 2 && BM == 128 && BN == 128)
@@ -372,6 +642,46 @@ static void wg_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   }
 }
 
+// which: 1 = DPA_WGRAD_X6Q (default 1): the 8-wave double-buffered fp32 (x6) kernel for filters of more than 64 output
+// channels (0 = the 4-wave kernel everywhere).  v >= 0 sets the knob and returns the previous value; v < 0 only reads it.
+DPA_API int dpa_wgrad_knob(int which, int v) {
+  static int cur[2] = {0, [] { const char* e = getenv("DPA_WGRAD_X6Q"); return e ? atoi(e) : 1; }()};
+  if (which != 1) return -1;
+  const int prev = cur[which];
+  if (v >= 0) cur[which] = v;
+  return prev;
+}
+
+template <int WM, int WN>
+static int x6q_launch(WgradParams& p, float* grad, float* workspace, hipStream_t s) {
+  constexpr int BM = WM * 64, BN = WN * 64, BKP = 32;
+  constexpr size_t LDS = (size_t)2 * 3 * BKP * (TrTile<BM * 2>::PITCH + TrTile<BN * 2>::PITCH);      // 144 KB
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6q_kernel<WM, WN>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+  if (attr != hipSuccess) return 1;
+  p.tilesM = (p.K + BM - 1) / BM;
+  p.tilesN = (p.Ng + BN - 1) / BN;
+  const int tiles = p.tilesM * p.tilesN;
+  const int ksteps = (p.P + BKP - 1) / BKP;
+  int split = 256 / tiles;          // one block per CU: at most one resident round
+  if (split > ksteps / 8) split = ksteps / 8;
+  if (split < 1) split = 1;
+  if (!workspace) split = 1;
+  int steps_per = (ksteps + split - 1) / split;
+  split = (ksteps + steps_per - 1) / steps_per;
+  p.splitK = split;
+  p.pixPerSplit = steps_per * BKP;
+  p.xcd_order = 1;
+  p.out = split == 1 ? grad : workspace;
+  hipLaunchKernelGGL((conv_wgrad_x6q_kernel<WM, WN>), dim3(tiles * split), dim3(512), LDS, s, p);
+  if (split > 1) {
+    const long long n = (long long)p.K * p.Ng;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, workspace, grad, n,
+                       split, p.accumulate);
+  }
+  return 0;
+}
+
 template <typename T>
 static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_t s) {
   constexpr int VEC = 16 / sizeof(T);
@@ -381,6 +691,16 @@ static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_
   if ((size_t)p.N * p.H * p.W >= 0x7fffffffull || (size_t)p.P >= 0x7fffffffull) return 2;
   p.fd_Wo = make_fastdiv(p.Wo); p.fd_Ho = make_fastdiv(p.Ho);
   p.fd_C = make_fastdiv(p.C); p.fd_S = make_fastdiv(p.S);
+  if constexpr (sizeof(T) == 4) {
+    // fp32 in x6 arithmetic, more than 64 filters: the 8-wave kernel with 256 x 128 or 128 x 256 tiles, where at most a
+    // fifth of a tile dimension is padding (ResNet-50: everything but the 64-filter layers and the 64-channel 1x1 convs)
+    if (dpa_get_fp32_mode() == 1 && dpa_wgrad_knob(1, -1) > 0 && p.Ng >= 128) {
+      const int padM256 = (p.K + 255) / 256 * 256 - p.K, padN128 = (p.Ng + 127) / 128 * 128 - p.Ng;
+      const int padM128 = (p.K + 127) / 128 * 128 - p.K, padN256 = (p.Ng + 255) / 256 * 256 - p.Ng;
+      if (p.K >= 256 && padM256 * 5 <= p.K && padN128 * 5 <= p.Ng) return x6q_launch<4, 2>(p, grad, workspace, s);
+      if (p.K > 64 && p.Ng >= 256 && padM128 * 5 <= p.K && padN256 * 5 <= p.Ng) return x6q_launch<2, 4>(p, grad, workspace, s);
+    }
+  }
   if (p.Ng <= 64 && p.K >= 256 && sizeof(T) == 4)
                        wg_launch<T, 4, 1, 4, 4>(p, grad, workspace, s);   // 256 x  64: 1x1 expand convs on 64 channels (fp32: the
                                                                           // operand splits are paid per staged element, and this
@@ -410,6 +730,9 @@ DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {
   const int bn = Ng <= 64 ? 64 : (K <= 64 ? ((Ng % 192 == 0 && Ng % 256 != 0) ? 192 : 256) : 128);
   const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bn - 1) / bn);
   long long split = (1024 + tiles - 1) / tiles;      // upper bound of what wg_launch may choose
+  const long long tq1 = (long long)((K + 255) / 256) * ((Ng + 127) / 128), tq2 = (long long)((K + 127) / 128) * ((Ng + 255) / 256);
+  const long long split_q = 256 / (tq1 < tq2 ? tq1 : tq2);      // x6q_launch: one round of 256 blocks
+  if (split < split_q) split = split_q;
   return split * (long long)K * Ng;
 }
 DPA_API int dpa_wgrad_params_size() { return (int)sizeof(WgradParams); }

@@ -82,6 +82,52 @@ def test_conv_fprop_dgrad_wgrad(shape, dtype, fp32_mode):
     torch.testing.assert_close(dw2 - 1.0, ref_dw, rtol=rtol, atol=max(atol * 10, scale * (3e-2 if dtype == torch.bfloat16 else 2e-5)))
 
 
+X6Q_SHAPES = [
+    (2, 14, 14, 256, 256, 3, 1, 1),    # 256 x 128 tiles
+    (2, 14, 14, 72, 480, 3, 1, 1),     # 256 x 128 tiles, ragged in both dimensions (K = 480, Ng = 648)
+    (3, 28, 28, 128, 128, 3, 1, 1),    # 128 x 256 tiles, Ng = 1152 (last tile half empty)
+    (2, 28, 28, 512, 128, 1, 1, 0),    # 128 x 256 tiles, 1x1
+    (2, 28, 28, 256, 512, 1, 2, 0),    # 1x1 stride 2
+    (1, 9, 9, 64, 256, 3, 2, 1),       # stride 2 with padding; 25 output pixels: less than ONE 32-pixel K-tile
+    (5, 7, 7, 512, 2048, 1, 1, 0),     # 245 pixels: 7.7 K-tiles, odd count of K-tiles per split
+]
+
+
+@pytest.mark.parametrize("shape", X6Q_SHAPES)
+def test_conv_wgrad_x6q_kernel(shape):
+    """conv_wgrad_x6q_kernel (fp32 x6, 8 waves, plane tiles double-buffered in LDS, staging interleaved with the MFMAs)
+    against the PyTorch reference and against the 4-wave kernel; split-K with a workspace, and one pass accumulating."""
+    from distributedpytorch_amd.ops import hip_conv, native
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    lib = native.hip_lib()
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(2468)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g)
+    wr = torch.zeros(K, C, k, k, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double(), wr, stride=s, padding=pd).backward(dy.permute(0, 3, 1, 2).double())
+    ref = wr.grad.permute(0, 2, 3, 1).float()
+    scale = ref.abs().max().item()
+    prev_mode = set_fp32_mode("x6")
+    prev = lib.dpa_wgrad_knob(1, 1)
+    try:
+        ws = torch.empty(hip_conv.wgrad_workspace_numel(K, k * k * C), device="cuda")
+        dw = torch.full((K, k, k, C), float("nan"), device="cuda")
+        hip_conv.conv_wgrad(dy, x, dw, (k, k), (s, s), (pd, pd), workspace=ws)
+        torch.testing.assert_close(dw, ref, rtol=1e-5, atol=scale * 2e-6)
+        dw1 = torch.ones_like(dw)
+        hip_conv.conv_wgrad(dy, x, dw1, (k, k), (s, s), (pd, pd), workspace=None, accumulate=True)
+        torch.testing.assert_close(dw1 - 1.0, ref, rtol=1e-5, atol=scale * 4e-6)
+        lib.dpa_wgrad_knob(1, 0)
+        dw0 = torch.full((K, k, k, C), float("nan"), device="cuda")
+        hip_conv.conv_wgrad(dy, x, dw0, (k, k), (s, s), (pd, pd), workspace=ws)
+        torch.testing.assert_close(dw, dw0, rtol=1e-5, atol=scale * 2e-6)
+    finally:
+        lib.dpa_wgrad_knob(1, prev)
+        set_fp32_mode(prev_mode)
+
+
 def test_conv_channel_slice_and_epilogue():
     """zero-copy concat: read a channel slice, write into a channel slice, fused bias+relu+addend."""
     from distributedpytorch_amd.ops import hip_conv
