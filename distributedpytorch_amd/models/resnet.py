@@ -13,6 +13,12 @@ from ..nn.layers import (AvgPool2d, BatchNorm2d, Conv2d, ConvBNAct, ConvBNReLUPo
 
 # DPA_FUSE_STEM_POOL=0: stem as conv+BN+ReLU followed by a separate max-pool (A/B switch for nn/layers.py:ConvBNReLUPool)
 _FUSE_STEM_POOL = os.environ.get("DPA_FUSE_STEM_POOL", "1") != "0"
+# DPA_RESNET_DOWN_LAST=0: in a block with a downsample branch run that branch FIRST (its stride-2 1x1 dgrad then only
+# accumulates into a quarter of the pixels of x.grad).  Default: conv1 first whenever the block's input came out of a
+# BatchNorm + ReLU, so that conv1's dgrad is the LAST contribution to x.grad and carries that BatchNorm's backward
+# reduction in its epilogue (nn/layers.py: Conv2d._bn_fusion) - one bn_bwd_reduce pass over dy, y and z of the previous
+# block's output less, against a full-tensor write + read of the downsample gradient.
+_DOWN_LAST = os.environ.get("DPA_RESNET_DOWN_LAST", "1") != "0"
 
 
 def _cb(store, prefix, conv_name, bn_name, cin, cout, k, stride, pad, trainable):
@@ -36,6 +42,10 @@ class BasicBlock:
         """sole_consumer: nothing but this block reads x (the caller's promise).  Then conv1's dgrad completes x.grad
         (the identity connection contributes earlier in the backward pass) and may carry the BatchNorm-backward
         reduction of the layer that produced x (ConvBNAct: last_use); conv2 is the only reader of conv1's output."""
+        if self.down is not None and _DOWN_LAST and sole_consumer and getattr(x, "bn_src", None) is not None:
+            out = self.c1(ctx, x, relu=True, last_use=True)       # see _DOWN_LAST
+            identity = self.down(ctx, x, relu=False)
+            return self.c2(ctx, out, relu=True, residual=identity, last_use=True)
         # the downsample branch runs FIRST so that, in the reversed backward order, its dgrad comes after conv1's and
         # accumulates in place into x.grad: the stride-2 1x1 dgrad then touches only 1/4 of the pixels
         identity = x if self.down is None else self.down(ctx, x, relu=False)
@@ -55,6 +65,11 @@ class Bottleneck:
             self.down = _cb(store, prefix, "downsample.0", "downsample.1", cin, planes * 4, 1, stride, 0, trainable)
 
     def __call__(self, ctx: Context, x: Act, sole_consumer=False) -> Act:
+        if self.down is not None and _DOWN_LAST and sole_consumer and getattr(x, "bn_src", None) is not None:
+            out = self.c1(ctx, x, relu=True, last_use=True)       # see _DOWN_LAST
+            out = self.c2(ctx, out, relu=True, last_use=True)
+            identity = self.down(ctx, x, relu=False)
+            return self.c3(ctx, out, relu=True, residual=identity, last_use=True)
         identity = x if self.down is None else self.down(ctx, x, relu=False)      # first: see BasicBlock
         out = self.c1(ctx, x, relu=True, last_use=sole_consumer and self.down is None)
         out = self.c2(ctx, out, relu=True, last_use=True)
