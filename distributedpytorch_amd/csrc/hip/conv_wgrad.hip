@@ -663,7 +663,14 @@ static int x6q_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   p.tilesN = (p.Ng + BN - 1) / BN;
   const int tiles = p.tilesM * p.tilesN;
   const int ksteps = (p.P + BKP - 1) / BKP;
-  int split = 256 / tiles;          // one block per CU: at most one resident round
+  // One block per CU.  The split-K factor fills whole rounds of the 256 block slots: the fewest rounds (at most three)
+  // whose last one is at least 93 % full (512 -> 512 3x3: 72 tiles, 3 x 72 = 216 blocks leave 16 % of the CUs idle for the
+  // whole kernel, 7 x 72 = 504 blocks fill two rounds to 98 %).
+  int split = 256 / tiles;
+  for (int r = 1; r <= 3; ++r) {
+    const int sr = 256 * r / tiles;
+    if (sr >= 1 && sr * tiles * 100 >= 93 * 256 * r) { split = sr; break; }
+  }
   if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
   if (!workspace) split = 1;
@@ -693,12 +700,12 @@ static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_
   p.fd_C = make_fastdiv(p.C); p.fd_S = make_fastdiv(p.S);
   if constexpr (sizeof(T) == 4) {
     // fp32 in x6 arithmetic, more than 64 filters: the 8-wave kernel with 256 x 128 or 128 x 256 tiles, where at most a
-    // fifth of a tile dimension is padding (ResNet-50: everything but the 64-filter layers and the 64-channel 1x1 convs)
+    // tenth of a tile dimension is padding (128 -> 128 3x3, Ng = 1152 = 4.5 tiles of 256: 3 % slower than the 4-wave kernel) (ResNet-50: everything but the 64-filter layers and the 64-channel 1x1 convs)
     if (dpa_get_fp32_mode() == 1 && dpa_wgrad_knob(1, -1) > 0 && p.Ng >= 128) {
       const int padM256 = (p.K + 255) / 256 * 256 - p.K, padN128 = (p.Ng + 127) / 128 * 128 - p.Ng;
       const int padM128 = (p.K + 127) / 128 * 128 - p.K, padN256 = (p.Ng + 255) / 256 * 256 - p.Ng;
-      if (p.K >= 256 && padM256 * 5 <= p.K && padN128 * 5 <= p.Ng) return x6q_launch<4, 2>(p, grad, workspace, s);
-      if (p.K > 64 && p.Ng >= 256 && padM128 * 5 <= p.K && padN256 * 5 <= p.Ng) return x6q_launch<2, 4>(p, grad, workspace, s);
+      if (p.K >= 256 && padM256 * 10 <= p.K && padN128 * 10 <= p.Ng) return x6q_launch<4, 2>(p, grad, workspace, s);
+      if (p.K > 64 && p.Ng >= 256 && padM128 * 10 <= p.K && padN256 * 10 <= p.Ng) return x6q_launch<2, 4>(p, grad, workspace, s);
     }
   }
   if (p.Ng <= 64 && p.K >= 256 && sizeof(T) == 4)
@@ -731,7 +738,7 @@ DPA_API long long dpa_conv_wgrad_workspace(int K, int Ng) {
   const long long tiles = (long long)((K + bm - 1) / bm) * ((Ng + bn - 1) / bn);
   long long split = (1024 + tiles - 1) / tiles;      // upper bound of what wg_launch may choose
   const long long tq1 = (long long)((K + 255) / 256) * ((Ng + 127) / 128), tq2 = (long long)((K + 127) / 128) * ((Ng + 255) / 256);
-  const long long split_q = 256 / (tq1 < tq2 ? tq1 : tq2);      // x6q_launch: one round of 256 blocks
+  const long long split_q = 768 / (tq1 < tq2 ? tq1 : tq2);      // x6q_launch: at most three rounds of 256 blocks
   if (split < split_q) split = split_q;
   return split * (long long)K * Ng;
 }

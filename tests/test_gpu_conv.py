@@ -84,8 +84,8 @@ def test_conv_fprop_dgrad_wgrad(shape, dtype, fp32_mode):
 
 X6Q_SHAPES = [
     (2, 14, 14, 256, 256, 3, 1, 1),    # 256 x 128 tiles
-    (2, 14, 14, 72, 480, 3, 1, 1),     # 256 x 128 tiles, ragged in both dimensions (K = 480, Ng = 648)
-    (3, 28, 28, 128, 128, 3, 1, 1),    # 128 x 256 tiles, Ng = 1152 (last tile half empty)
+    (2, 14, 14, 120, 480, 3, 1, 1),    # 256 x 128 tiles, ragged in both dimensions (K = 480, Ng = 1080)
+    (3, 28, 28, 136, 120, 3, 1, 1),    # 128 x 256 tiles, ragged in both dimensions (K = 120, Ng = 1224)
     (2, 28, 28, 512, 128, 1, 1, 0),    # 128 x 256 tiles, 1x1
     (2, 28, 28, 256, 512, 1, 2, 0),    # 1x1 stride 2
     (1, 9, 9, 64, 256, 3, 2, 1),       # stride 2 with padding; 25 output pixels: less than ONE 32-pixel K-tile
