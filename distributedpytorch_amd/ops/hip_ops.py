@@ -12,7 +12,7 @@ from .hip_conv import (conv_dgrad, conv_fprop, conv_wgrad, out_size, stats_rows,
 from .native import F32, I32, I64, VP, ptr, stream_ptr
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
-ROWS_L2 = 128
+ROWS_L2 = 256
 
 
 class PoolP(ctypes.Structure):
