@@ -159,6 +159,16 @@ __device__ __forceinline__ void split3_pair(float x, float y, uint32_t (&o)[3]) 
 __device__ constexpr int kX6A[6] = {1, 2, 0, 1, 0, 0};
 __device__ constexpr int kX6B[6] = {1, 0, 2, 0, 1, 0};
 
+// ---- LDS-DMA from inline asm ----------------------------------------------------------------------------------------
+// One 1-KiB LDS-DMA piece issued from inline asm: hipcc does not count it, so it puts no s_waitcnt vmcnt(0) in front of
+// the LDS reads that follow (it does for the builtin: it cannot tell that they read another buffer) - the K loops that use it wait for its DMAs itself, once per K-tile.  M0 (the LDS destination) is saved and restored inside the
+// statement (cdna_hip_programming.md §5.7).  lds_addr must be wave-uniform.
+__device__ __forceinline__ void dpa_glds16(const void* g, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
 // ---- fused BatchNorm-backward reduction (dgrad epilogues of conv_igemm.hip and conv_x6p.hip) --------------------------
 // One lane owns VEC consecutive channels of a few rows of the tile.
 template <typename T, int VEC>

@@ -14,6 +14,9 @@
 //   tile is staged through LDS so global stores are 16 B per lane along the channel dimension, at an
 //   arbitrary channel offset/stride of the destination buffer (zero-copy concat).
 #include "conv_common.h"
+#ifndef DPA_GLDS_EARLY
+#define DPA_GLDS_EARLY 1      // 0: the round-2 loop (DMA issued behind the fragment reads through the builtin); A/B builds
+#endif
 #include <map>
 #include <mutex>
 #include <cstdlib>
@@ -254,6 +257,51 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
     // compiler puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA (it cannot tell the two
     // buffers apart), which would wait for the prefetch right after issuing it and expose the whole global latency
     // every K-tile (measured: 63 % MFMA utilisation in fp32, profiles/README.md).
+#if DPA_GLDS_EARLY
+    // Round 3: the DMA of tile kt + 1 is issued FIRST in iteration kt, right behind the barrier, from inline asm
+    // (dpa_glds16: hipcc does not count it, so the fragment reads behind it get no vmcnt(0)) - it has the whole iteration
+    // to land instead of the MFMAs' 512 cycles, and its source addresses were generated under the previous tile's MFMAs.
+    typedef __attribute__((address_space(3))) char lds_char;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_char*)smem);
+    auto issue_asm = [&](int buf) __attribute__((always_inline)) {     // after gen_addresses(kt)
+      const uint32_t stage = lds0 + buf * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) dpa_glds16(pa[i], stage + (i * 32 + wave_u * 8) * 128);
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i) dpa_glds16(pb[i], stage + BM * 128 + (i * 32 + wave_u * 8) * 128);
+    };
+    gen_addresses(kt0);      // (splits are never empty; a zero-tap dgrad class has all loads predicated to the zero chunk)
+    issue_asm(0);
+    if (kt0 + 1 < nkt) gen_addresses(kt0 + 1);
+    for (int kt = kt0; kt < nkt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nkt) issue_asm((kt + 1 - kt0) & 1);
+      const char* tA = smem + ((kt - kt0) & 1) * STAGE_BYTES;
+      const char* tB = tA + BM * 128;
+      uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[ks][i] = *reinterpret_cast<const uint4*>(tA + lds_off(wm * TM * 16 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[ks][j] = *reinterpret_cast<const uint4*>(tB + lds_off(wn * TN * 16 + j * 16 + fr, ks * 4 + fq));
+      }
+      if (kt + 2 < nkt) gen_addresses(kt + 2);
+      if constexpr (X6) {
+        mma_x6(fa, fb);
+      } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) MfmaT<T>::mma(fa[ks][i], fb[ks][j], acc[i][j]);
+      }
+    }
+#else
     gen_addresses(kt0);      // (splits are never empty; a zero-tap dgrad class has all loads predicated to the zero chunk)
     issue_tile(0);
     for (int kt = kt0; kt < nkt; ++kt) {
@@ -283,6 +331,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
           for (int j = 0; j < TN; ++j) MfmaT<T>::mma(fa[ks][i], fb[ks][j], acc[i][j]);
       }
     }
+#endif
     __syncthreads();
   } else {
     gen_addresses(kt0);

@@ -177,15 +177,6 @@ DPA_API int dpa_weight_prep(const void* segs, int nsegs, long long total_chunks,
 }
 DPA_API int dpa_weight_prep_seg_size() { return (int)sizeof(WPrepSeg); }
 
-// One 1-KiB LDS-DMA piece issued from inline asm: hipcc does not count it, so it puts no s_waitcnt vmcnt(0) in front of
-// the LDS reads that follow (it does for the builtin: it cannot tell that they read another buffer) - the pipelined K
-// loop below waits for its DMAs itself, once per K-tile.  M0 (the LDS destination) is saved and restored inside the
-// statement (cdna_hip_programming.md §5.7).  lds_addr must be wave-uniform.
-__device__ __forceinline__ void x6p_glds16(const void* g, uint32_t lds_addr) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
-}
 template <int V> struct X6pInt { static constexpr int value = V; };
 
 // NW = 4 waves per block, stacked along M; each wave owns TMW = 2 row tiles of 16 rows: a 128 x BN block tile, two blocks
@@ -435,7 +426,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
           const float* pa = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
-          x6p_glds16(pa, lds0 + par * A_BYTES + (i * RPP + wave * 8) * 128);
+          dpa_glds16(pa, lds0 + par * A_BYTES + (i * RPP + wave * 8) * 128);
         }
       };
       auto issue_B = [&](int kt, int par) __attribute__((always_inline)) {
@@ -451,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i)
           if ((3 * TN) % NW == 0 || wave + NW * i < 3 * TN)          // wave-uniform
-            x6p_glds16(wgt3 + b_off[i] + woff, lds0 + B_BASE + par * 3 * BP_BYTES + (b_lds[i] - A_BYTES));
+            dpa_glds16(wgt3 + b_off[i] + woff, lds0 + B_BASE + par * 3 * BP_BYTES + (b_lds[i] - A_BYTES));
       };
       auto read_A = [&](int par, uint4 (&lo)[TM], uint4 (&hi)[TM]) __attribute__((always_inline)) {
         const char* tA = smem + par * A_BYTES;
