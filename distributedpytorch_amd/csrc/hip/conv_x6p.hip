@@ -262,6 +262,8 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void gbl_void;
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_char_t*)smem);
   auto issue_tile = [&](int kt, int buf) __attribute__((always_inline)) {
     const uint32_t k0 = (uint32_t)kt * BKE;                       // wave-uniform
     const uint32_t tap = fd_div(k0, p.fd_sC);
@@ -271,16 +273,18 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     const long long delta = (long long)(DGRAD ? -(r * p.sW + s) : (r * p.sW + s)) * p.s_cs + cbase;
     const int woff = DGRAD ? (((p.tap_r0 + p.sh * r) * p.S + p.tap_s0 + p.sw * s) * p.sC + cbase) : (int)k0;
     const uint32_t bit = 1u << tap;
-    char* stage = smem + buf * STAGE_BYTES;
+    // (from inline asm, dpa_glds16: hipcc does not count these, so the fragment reads behind them get no vmcnt(0) and the
+    // DMA can be issued first in the iteration)
+    const uint32_t stage = lds_base + buf * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const float* pa = (a_mask[i] & bit) ? src + (a_rowoff[i] + delta) : zero;
-      __builtin_amdgcn_global_load_lds((gbl_void*)pa, (lds_void*)(stage + (i * RPP + wave * 8) * 128), 16, 0, 0);
+      dpa_glds16(pa, stage + (i * RPP + wave * 8) * 128);
     }
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i)
       if ((3 * TN) % NW == 0 || wave + NW * i < 3 * TN)          // wave-uniform
-        __builtin_amdgcn_global_load_lds((gbl_void*)(wgt3 + b_off[i] + woff), (lds_void*)(stage + b_lds[i]), 16, 0, 0);
+        dpa_glds16(wgt3 + b_off[i] + woff, stage + b_lds[i]);
   };
 
   const int nkt = (p.Kg + BKE - 1) / BKE;
@@ -539,6 +543,11 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     for (int kt = 0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      // short reductions (fewer than four K-tiles: the 56x56 1x1 layers on 64 channels): the next tile's DMA first - its
+      // buffer was read during iteration kt - 1 - so that it has the whole iteration to land (+4-10 % on those layers;
+      // the 64 -> 64 3x3 layers, 18 K-tiles, lose 3 % that way and keep the issue behind the fragment reads)
+      const bool early = nkt < 4;                                        // block-uniform
+      if (early && kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1);
       const char* tA = smem + (kt & 1) * STAGE_BYTES;
       const char* tB = tA + A_BYTES;
       uint4 fa[2][TM];
@@ -554,7 +563,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 #pragma unroll
         for (int part = 0; part < 3; ++part)
           bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + j * 1024 + b_frag);
-      if constexpr (TN <= 4) { if (kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1); }
+      if constexpr (TN <= 4) { if (!early && kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1); }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if constexpr (ABL & 1) { ap[i][0] = fa[0][i]; ap[i][1] = fa[1][i]; ap[i][2] = fa[0][i]; }
@@ -570,14 +579,13 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
             else MfmaT<bf16_t>::mma(ap[i][kX6A[t]], bp[j][kX6B[t]], acc[i][j]);
           }
       if constexpr (TN > 4) {
-        // second half of the filter fragments: read them, THEN issue the next tile's DMA (the compiler puts
-        // s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA issue), then the other 48 MFMAs
+        // second half of the filter fragments, then the next tile's DMA, then the other 48 MFMAs
 #pragma unroll
         for (int j = 0; j < JH; ++j)
 #pragma unroll
           for (int part = 0; part < 3; ++part)
             bp[j][part] = *reinterpret_cast<const uint4*>(tB + part * BP_BYTES + (JH + j) * 1024 + b_frag);
-        if (kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1);
+        if (!early && kt + 1 < nkt && (!(ABL & 2) || kt < 1)) issue_tile(kt + 1, (kt + 1) & 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
