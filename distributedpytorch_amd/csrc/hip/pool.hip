@@ -303,10 +303,82 @@ __global__ void __launch_bounds__(256) adaptive_avgpool_bwd_kernel(const T* __re
     else            hipLaunchKernelGGL(kern<float>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);                \
   } while (0)
 
+// 3x3 windows (any stride / padding): the nine loads of a window are issued together, unconditionally (clamped coordinates,
+// a validity bit per tap), before the first comparison - the general kernel above walks the window with two runtime loops and
+// a branch per tap, i.e. nine dependent round trips per output (ResNet-50 stem at batch 1024: 1.48 ms for 4.3 GB).
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_k3_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                             unsigned char* __restrict__ idx, PoolP p,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = p.C / VEC;
+  const long long total = (long long)p.N * p.Ho * p.Wo * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % cpr) * VEC;
+    long long t = i / cpr;
+    const int wo = (int)(t % p.Wo); t /= p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    const int h0 = ho * p.sh - p.ph, w0 = wo * p.sw - p.pw;
+    Vec16<T> v[9];
+    unsigned valid = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int hi = h0 + r, wi = w0 + s;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        valid |= (ok ? 1u : 0u) << (r * 3 + s);
+        const int hc = min(max(hi, 0), p.H - 1), wc = min(max(wi, 0), p.W - 1);
+        v[r * 3 + s].load(x + ((long long)(n * p.H + hc) * p.W + wc) * p.x_cs + c);
+      }
+    float best[VEC]; unsigned char bi[VEC];
+    float sc[VEC], sf[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; sc[e] = scale ? scale[c + e] : 1.f; sf[e] = scale ? shift[c + e] : 0.f; }
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const bool ok = (valid >> k) & 1u;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float f = v[k].get(e);
+        if (scale) { f = fmaxf(f * sc[e] + sf[e], 0.f); if (sizeof(T) == 2) f = bf2f(f2bf(f)); }
+        if (ok && (first || f > best[e] || f != f)) { best[e] = f; bi[e] = (unsigned char)k; }
+      }
+      first = first && !ok;
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, best[e]);
+    const long long opix = (long long)(n * p.Ho + ho) * p.Wo + wo;
+    o.store(y + opix * p.y_cs + c);
+    if (idx) {
+      unsigned char* ip = idx + opix * p.C + c;
+      if (VEC == 8) { uint2 pk; unsigned char* b = (unsigned char*)&pk;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) b[e] = bi[e];
+        *reinterpret_cast<uint2*>(ip) = pk;
+      } else { uint32_t pk; unsigned char* b = (unsigned char*)&pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = bi[e];
+        *reinterpret_cast<uint32_t*>(ip) = pk;
+      }
+    }
+  }
+}
+
 DPA_API int dpa_maxpool_fwd(const void* x, void* y, unsigned char* idx, const PoolP* pp, int dtype, hipStream_t s,
                              const float* scale, const float* shift) {
   PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
   const long long total = (long long)p.N * p.Ho * p.Wo * (p.C / vec);
+  static const int fast3 = [] { const char* e = getenv("DPA_POOL_K3"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (fast3 && p.kh == 3 && p.kw == 3) {
+    if (dtype == 1) hipLaunchKernelGGL(maxpool_fwd_k3_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, p, scale, shift);
+    else            hipLaunchKernelGGL(maxpool_fwd_k3_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, idx, p, scale, shift);
+    return dpa_launch_rc();
+  }
   if (dtype == 1) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, p, scale, shift);
   else            hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, idx, p, scale, shift);
   return dpa_launch_rc();

@@ -56,9 +56,11 @@ def _run(tmp_path, world, plan, extra_env=None, limit_s=20):
 def test_all_ranks_converge_on_the_fallback_when_one_native_worker_dies(tmp_path):
     # attempt 0 (native): rank 1 dies at once, ranks 0 and 2 would hang for ever (a collective with a dead peer)
     plan = {"0:1": "fail:17", "0:0": "hang", "0:2": "hang"}
-    rcs, outs, took = _run(tmp_path, 3, plan)
+    rcs, outs, took = _run(tmp_path, 3, plan, limit_s=60)
     assert rcs == [0, 0, 0], (rcs, [o[1][-800:] for o in outs])
-    assert took < 15, took                                       # not the 20 s attempt limit, let alone the 300 s hang
+    # not the 60 s attempt limit, let alone the 300 s hang (a few seconds on an idle machine; the bound leaves room for six
+    # interpreter starts with `import torch` on a machine that is busy building)
+    assert took < 45, took
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1, outs[0][0]                           # ONE JSON line, from the attempt everyone finished
     d = json.loads(lines[0])
@@ -94,5 +96,5 @@ def test_both_attempts_failing_exits_non_zero_without_a_number(tmp_path):
 def test_attempt_time_limit_kills_a_hung_job(tmp_path):
     rcs, outs, took = _run(tmp_path, 2, {"0:*": "hang"}, limit_s=3)
     assert rcs == [0, 0], (rcs, [o[1][-800:] for o in outs])
-    assert took < 25
+    assert took < 40
     assert json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][0])["backend"] == "torch"
