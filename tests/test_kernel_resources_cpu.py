@@ -57,10 +57,23 @@ def test_presplit_kernels_keep_their_residency_without_scratch(tmp_path):
     """conv_x6p.hip: every instantiation of the production tile (two blocks per CU: <= 256 registers) and of the narrow
     tile fits two waves per SIMD with no scratch."""
     res = {k: v for k, v in _resources(os.path.join(HIP_DIR, "conv_x6p.hip"), tmp_path).items() if "conv_x6p_kernel" in k}
-    assert len(res) == 6, f"expected the six production instantiations of conv_x6p_kernel, found {len(res)}"
+    # six tiles with the plain double-buffered K loop + the software-pipelined loop of the wide tile (fprop, dgrad)
+    assert len(res) == 8, f"expected the eight production instantiations of conv_x6p_kernel, found {len(res)}"
+    assert sum(k.endswith("Lb1EEv10ConvParams") for k in res) == 2, list(res)
     bad = {}
     for k, v in res.items():
-        short = k.endswith("Li1EEv10ConvParams")           # the 64 x 64 tile is built for three blocks per CU
+        # template <TN, DGRAD, NW, MF, TMW, ABL, PIPE>: TMW == 1 is the 64 x 64 tile, built for three blocks per CU
+        short = re.search(r"ELi1ELi0ELb[01]EEv10ConvParams$", k) is not None
         if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < (3 if short else 2):
             bad[k] = v
+    assert not bad, "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_eight_wave_wgrad_kernel_has_no_scratch(tmp_path):
+    """conv_wgrad.hip's 8-wave x6 kernel: one 512-thread block per CU (144 KB of LDS) = two waves per SIMD, which leaves
+    256 registers a lane; both instantiations must stay clear of scratch."""
+    res = {k: v for k, v in _resources(os.path.join(HIP_DIR, "conv_wgrad.hip"), tmp_path).items() if "conv_wgrad_x6q_kernel" in k}
+    assert len(res) == 2, list(res)
+    bad = {k: v for k, v in res.items() if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < 2}
     assert not bad, "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
