@@ -658,7 +658,10 @@ static int x6q_launch(WgradParams& p, float* grad, float* workspace, hipStream_t
   constexpr size_t LDS = (size_t)2 * 3 * BKP * (TrTile<BM * 2>::PITCH + TrTile<BN * 2>::PITCH);      // 144 KB
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_x6q_kernel<WM, WN>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-  if (attr != hipSuccess) return 1;
+  if (attr != hipSuccess) {      // no 144 KB of dynamic LDS on this device / runtime: the caller takes the 4-wave kernel
+    (void)hipGetLastError();
+    return -1;
+  }
   p.tilesM = (p.K + BM - 1) / BM;
   p.tilesN = (p.Ng + BN - 1) / BN;
   const int tiles = p.tilesM * p.tilesN;
@@ -704,8 +707,10 @@ static int wg_dispatch(WgradParams& p, float* grad, float* workspace, hipStream_
     if (dpa_get_fp32_mode() == 1 && dpa_wgrad_knob(1, -1) > 0 && p.Ng >= 128) {
       const int padM256 = (p.K + 255) / 256 * 256 - p.K, padN128 = (p.Ng + 127) / 128 * 128 - p.Ng;
       const int padM128 = (p.K + 127) / 128 * 128 - p.K, padN256 = (p.Ng + 255) / 256 * 256 - p.Ng;
-      if (p.K >= 256 && padM256 * 10 <= p.K && padN128 * 10 <= p.Ng) return x6q_launch<4, 2>(p, grad, workspace, s);
-      if (p.K > 64 && p.Ng >= 256 && padM128 * 10 <= p.K && padN256 * 10 <= p.Ng) return x6q_launch<2, 4>(p, grad, workspace, s);
+      int rc = -1;
+      if (p.K >= 256 && padM256 * 10 <= p.K && padN128 * 10 <= p.Ng) rc = x6q_launch<4, 2>(p, grad, workspace, s);
+      else if (p.K > 64 && p.Ng >= 256 && padM128 * 10 <= p.K && padN256 * 10 <= p.Ng) rc = x6q_launch<2, 4>(p, grad, workspace, s);
+      if (rc >= 0) return rc;
     }
   }
   if (p.Ng <= 64 && p.K >= 256 && sizeof(T) == 4)
