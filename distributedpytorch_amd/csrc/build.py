@@ -29,7 +29,7 @@ HIP_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-r
 # -ffast-math only where it was measured to matter: the convolution translation units (MFMA builtins are unaffected;
 # the epilogues' scalar math is).  The optimizer, BatchNorm, loss, pooling, elementwise and augmentation kernels divide,
 # take square roots and are tested for inf / NaN propagation: they are built with IEEE semantics.
-FAST_MATH_TUS = {"conv_igemm.hip", "conv_x6p.hip", "conv_wgrad.hip"}
+FAST_MATH_TUS = {"conv_igemm.hip", "conv_x6p.hip", "conv_x6s.hip", "conv_wgrad.hip"}
 HOST_FLAGS = ["-O2", "-fPIC", "-std=c++17", "-Wall", "-pthread"]
 
 

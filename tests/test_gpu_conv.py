@@ -352,3 +352,82 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
         scale_q = (wd * xh).abs().sum(0).clamp_min(1e-6)
         assert ((got[0] - ref_s).abs() / scale_s).max().item() < 2e-6
         assert ((got[1] - ref_q).abs() / scale_q).max().item() < 2e-6
+
+
+@pytest.fixture
+def x6s_small():
+    """Let small problems take the persistent streaming kernel (conv_x6s.hip): 16 resident blocks instead of 512."""
+    from distributedpytorch_amd.ops import native
+    lib = native.hip_lib()
+    prev = lib.dpa_x6s_knob(2, 16), lib.dpa_x6p_min_tiles(1), lib.dpa_x6p_knob(1, 0), lib.dpa_x6p_knob(2, 0)
+    yield lib
+    lib.dpa_x6s_knob(2, prev[0]); lib.dpa_x6p_min_tiles(prev[1]); lib.dpa_x6p_knob(1, prev[2]); lib.dpa_x6p_knob(2, prev[3])
+
+
+# (N, H, W, Cout): 1x1 / stride 1 on 64 input channels; M = N H W is not a multiple of the 128-row tile
+X6S_SHAPES = [(5, 37, 29, 64), (5, 37, 29, 256), (9, 32, 32, 128)]
+
+
+@pytest.mark.parametrize("shape", X6S_SHAPES)
+def test_conv_streaming_x6_kernel(shape, x6s_small):
+    """csrc/hip/conv_x6s.hip (persistent blocks, filter planes resident in LDS, next activation tile in flight, stores straight
+    from the accumulators) against the fp32 PyTorch reference and against conv_x6p.hip's kernel, whose bits it must
+    reproduce: fprop with bias + shifted BatchNorm statistics, addend + ReLU into a channel slice, dgrad fresh and
+    accumulating in place."""
+    from distributedpytorch_amd.ops import hip_conv
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    lib = x6s_small
+    N, H, W, K = shape
+    C = 64
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    w = torch.randn(K, 1, 1, C, device="cuda", generator=g) * C ** -0.5
+    b = torch.randn(K, device="cuda", generator=g)
+    shift = torch.randn(K, device="cuda", generator=g) * 0.1
+    M = N * H * W
+    prev = set_fp32_mode("x6")
+    try:
+        w3 = hip_conv.split3_planes(w, torch.empty(3 * w.numel(), device="cuda", dtype=torch.bfloat16))
+        add = torch.randn(N, H, W, K + 16, device="cuda", generator=g)
+        out = {}
+        for on in (1, 0):
+            lib.dpa_x6s_knob(1, on)
+            y = torch.full((N, H, W, K), float("nan"), device="cuda")
+            stats = torch.full(((M + 63) // 64, 2, K), float("nan"), device="cuda")
+            hip_conv.conv_fprop(x, w, y, (1, 1), (0, 0), bias=b, stats=stats, stats_shift=shift, w3=w3)
+            rows = hip_conv.last_stats_rows[0]
+            buf = torch.zeros(N, H, W, K + 16, device="cuda")
+            hip_conv.conv_fprop(x, w, buf[..., 8:8 + K], (1, 1), (0, 0), bias=b, relu=True, addend=add[..., 8:8 + K], w3=w3)
+            out[on] = (y, stats[:rows].double().sum(0), rows, buf)
+        tilesN = 1 if K == 64 else K // 128
+        assert out[1][2] == max(8, (16 // tilesN) & ~7) and out[0][2] == (M + 127) // 128      # the streaming kernel ran / did not
+        y, st, _, buf = out[1]
+        assert torch.equal(y, out[0][0]) and torch.equal(buf, out[0][3])
+        yr = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b).permute(0, 2, 3, 1)
+        rtol, atol = _tol(torch.float32, C)
+        torch.testing.assert_close(y, yr, rtol=rtol, atol=atol * 10)
+        yc = (y.double() - shift.double()).reshape(-1, K)
+        torch.testing.assert_close(st[0], yc.sum(0), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(st[1], (yc * yc).sum(0), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(buf[..., 8:8 + K], (yr + add[..., 8:8 + K]).clamp_min(0), rtol=rtol, atol=atol * 10)
+        assert buf[..., :8].abs().max() == 0 and buf[..., 8 + K:].abs().max() == 0
+        # dgrad of a 1x1 conv K -> 64 ... is the same GEMM with the transposed filter: dy has 64 channels here
+        dy = torch.randn(N, H, W, C, device="cuda", generator=g)
+        wf = torch.randn(C, 1, 1, K, device="cuda", generator=g) * K ** -0.5         # forward filter of a K -> 64 conv
+        wt = wf.permute(3, 1, 2, 0).contiguous()                                     # [K][1][1][64]
+        wt3 = hip_conv.split3_planes(wt, torch.empty(3 * wt.numel(), device="cuda", dtype=torch.bfloat16))
+        ref_dx = torch.nn.grad.conv2d_input((N, K, H, W), wf.permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        res = {}
+        for on in (1, 0):
+            lib.dpa_x6s_knob(1, on)
+            dx = torch.full((N, H, W, K), float("nan"), device="cuda")
+            hip_conv.conv_dgrad(dy, wt, dx, (1, 1), (0, 0), wt3=wt3)
+            acc = add[..., :K].contiguous()
+            hip_conv.conv_dgrad(dy, wt, acc, (1, 1), (0, 0), addend=acc, wt3=wt3)
+            res[on] = (dx, acc)
+        assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])
+        torch.testing.assert_close(res[1][0], ref_dx, rtol=rtol, atol=atol * 10)
+        torch.testing.assert_close(res[1][1], add[..., :K] + ref_dx, rtol=rtol, atol=atol * 10)
+    finally:
+        lib.dpa_x6s_knob(1, 1)
+        set_fp32_mode(prev)
