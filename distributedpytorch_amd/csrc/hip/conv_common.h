@@ -169,6 +169,18 @@ __device__ __forceinline__ void dpa_glds16(const void* g, uint32_t lds_addr) {
                : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
 
+// Two pieces from a wave-uniform base (SGPR pair) + a 32-bit lane offset: bytes [0, 16) of every lane's address go to
+// lds_a, bytes [128, 144) to lds_b.  No 64-bit vector address arithmetic at all (conv_x6s.hip: a row's two K-tile halves).
+// The instruction's immediate offset is added to the LDS address as well as to the global one (observed: with M0 = lds_b
+// the second piece landed 128 bytes further), so M0 for the second piece is lds_b - 128.
+__device__ __forceinline__ void dpa_glds16x2_s(const void* sbase, uint32_t voff, uint32_t lds_a, uint32_t lds_b) {
+  uint32_t keep;
+  lds_b -= 128u;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+               "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:128\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_a), "s"(lds_b) : "memory");
+}
+
 // ---- fused BatchNorm-backward reduction (dgrad epilogues of conv_igemm.hip and conv_x6p.hip) --------------------------
 // One lane owns VEC consecutive channels of a few rows of the tile.
 template <typename T, int VEC>

@@ -360,12 +360,13 @@ def x6s_small():
     from distributedpytorch_amd.ops import native
     lib = native.hip_lib()
     prev = lib.dpa_x6s_knob(2, 16), lib.dpa_x6p_min_tiles(1), lib.dpa_x6p_knob(1, 0), lib.dpa_x6p_knob(2, 0)
+    lib.x6s_slots_expected = lambda tiles_n: max(8, (16 // tiles_n) & ~7)
     yield lib
     lib.dpa_x6s_knob(2, prev[0]); lib.dpa_x6p_min_tiles(prev[1]); lib.dpa_x6p_knob(1, prev[2]); lib.dpa_x6p_knob(2, prev[3])
 
 
 # (N, H, W, Cout): 1x1 / stride 1 on 64 input channels; M = N H W is not a multiple of the 128-row tile
-X6S_SHAPES = [(5, 37, 29, 64), (5, 37, 29, 256), (9, 32, 32, 128)]
+X6S_SHAPES = [(6, 37, 29, 64), (6, 37, 29, 256), (9, 32, 32, 128)]
 
 
 @pytest.mark.parametrize("shape", X6S_SHAPES)
@@ -400,7 +401,7 @@ def test_conv_streaming_x6_kernel(shape, x6s_small):
             hip_conv.conv_fprop(x, w, buf[..., 8:8 + K], (1, 1), (0, 0), bias=b, relu=True, addend=add[..., 8:8 + K], w3=w3)
             out[on] = (y, stats[:rows].double().sum(0), rows, buf)
         tilesN = 1 if K == 64 else K // 128
-        assert out[1][2] == max(8, (16 // tilesN) & ~7) and out[0][2] == (M + 127) // 128      # the streaming kernel ran / did not
+        assert out[1][2] == lib.x6s_slots_expected(tilesN) and out[0][2] == (M + 127) // 128      # the streaming kernel ran / did not
         y, st, _, buf = out[1]
         assert torch.equal(y, out[0][0]) and torch.equal(buf, out[0][3])
         yr = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b).permute(0, 2, 3, 1)

@@ -77,3 +77,13 @@ def test_eight_wave_wgrad_kernel_has_no_scratch(tmp_path):
     assert len(res) == 2, list(res)
     bad = {k: v for k, v in res.items() if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < 2}
     assert not bad, "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_streaming_kernel_keeps_two_blocks_per_cu_without_scratch(tmp_path):
+    """conv_x6s.hip: two 4-wave blocks per CU (80 KB of LDS each) = two waves per SIMD; a spill inside its loop would be
+    reloaded behind a wait for ALL outstanding stores."""
+    res = {k: v for k, v in _resources(os.path.join(HIP_DIR, "conv_x6s.hip"), tmp_path).items() if "conv_x6s_kernel" in k}
+    assert len(res) == 6, list(res)
+    bad = {k: v for k, v in res.items() if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < 2}
+    assert not bad, "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
