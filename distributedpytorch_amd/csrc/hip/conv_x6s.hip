@@ -6,15 +6,15 @@
 // 192 MFMAs per wave, an epilogue staged through LDS - a chain of latencies that two resident blocks per CU overlap only
 // by chance (profiles/r2_conv_layers_fp32_bs1024.txt: 85 TF-equivalent, 1434 us of which 1015 us without the stores and
 // 545 us for the stores alone: the phases ADD).  Here:
-//   * a block is resident for the whole launch and walks over M-tiles tm = slot, slot + nslots, ... of ONE column tile: the
-//     filter planes of that column tile (all 64 reduction elements, 48 KB) are staged once;
-//   * the activation tile of the NEXT M-tile is in flight (LDS-DMA, issued right after every wave has its fragments of the
-//     current one in registers) while the current tile is multiplied and stored;
+//   * a block is resident for the whole launch and bound to ONE column tile: the filter planes of that column tile (all 64
+//     reduction elements, 48 KB) are staged once; its waves walk over 32-row strips of the activations;
+//   * the activation strip AFTER the next one is in flight (LDS-DMA into the wave's own buffer, issued as soon as the wave
+//     has the next strip's fragments in registers) while the current strip is multiplied and stored;
 //   * the epilogue stores straight from the accumulator layout - lanes 0..15 of a quarter wave hold 16 consecutive
-//     channels of one pixel: 64-byte segments, scalar base + 32-bit lane offset + immediate - no LDS staging, so the
-//     activation buffer is free for the next tile's DMA during the whole epilogue;
-//   * BatchNorm statistics are carried in registers across the block's tiles and written once: nslots slab rows instead
-//     of one per M-tile.
+//     channels of one pixel: 64-byte segments, one address per row + the column tile in the immediate offset - no LDS
+//     staging, so the activation buffer belongs to the DMA during the whole epilogue;
+//   * BatchNorm statistics are carried in registers across a wave's strips and written once per block: nslots slab rows
+//     instead of one per M-tile.
 // Same arithmetic as conv_x6p.hip (same fragment layouts, same order of the six partial products and of the K-tiles): the
 // outputs are bit-identical to that kernel's.
 #include "conv_common.h"
@@ -28,7 +28,8 @@ template <int V> struct X6sInt { static constexpr int value = V; };
 // STATS / ADD: BatchNorm statistics / an addend in the epilogue (host: p.stats, p.addend).
 // Measured and dropped (profiles/r3_x6s_streaming_kernel.txt): 8 waves in one block per CU (the same), 12 waves (spills;
 // 10 % slower), 64-column tiles with 8 or 12 waves per CU (the operand split is done twice as often: 19 % slower), the
-// loop without the rotation below (2 % slower).
+// loop without the rotation below (9 % slower with block-wide barriers, 2 % with private buffers), a counted vmcnt wait
+// that leaves the previous strip's stores in flight (the same).
 template <int TN, bool STATS, bool ADD>
 __global__ void __launch_bounds__(256, 2) conv_x6s_kernel(const ConvParams p, const int nslots) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
