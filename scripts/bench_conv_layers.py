@@ -9,6 +9,8 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--only", default="")
+ap.add_argument("--bnr", action="store_true", help="dgrad as the training step runs it for a BatchNorm+residual+ReLU input: in-place "
+                "accumulation (addend) + the fused BatchNorm-backward reduction with the mask from y; adds a column with its time and traffic")
 ap.add_argument("--net", default="resnet50", choices=["resnet50", "resnet18_cifar", "resnet18"],
                 help="resnet18_cifar: BASELINE config 4 (ResNet-18 on 32x32 inputs: 3x3 stem, no max-pool; maps 32/16/8/4)")
 a = ap.parse_args()
@@ -61,6 +63,14 @@ for (h, ci, co, k, s, p, cnt) in LAYERS:
     tf = timeit(lambda: H.conv_fprop(x, w, y, (s, s), (p, p), stats=stats, w3=w3))
     td = timeit(lambda: H.conv_dgrad(dy, wt, dx, (s, s), (p, p), wt3=wt3))
     tw = timeit(lambda: H.conv_wgrad(dy, x, dw, (k, k), (s, s), (p, p), workspace=ws))
+    extra = ""
+    if a.bnr and k >= s:
+        z = torch.randn_like(x); yy = torch.randn_like(x)
+        mean = torch.zeros(ci, device="cuda"); inv = torch.ones(ci, device="cuda")
+        slab = torch.empty(H.bn_reduce_rows(N * h * h, (s, s)), 2, ci, device="cuda")
+        tb = timeit(lambda: H.conv_dgrad(dy, wt, dx, (s, s), (p, p), addend=dx, wt3=wt3, bn_reduce=(z, yy, mean, inv, None, None, slab)))
+        gb = (dy.numel() + 4 * dx.numel()) * dx.element_size() / 1e9
+        extra = f" | fused dgrad {tb*1e6:8.1f} us {gb / tb / 1e3:5.2f} TB/s (+{(tb - td)*1e6:6.1f} us)"
     tot["fprop"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
-    print(f"{name:34s} {fl/1e9:8.1f} | {tf*1e6:9.1f} {fl/tf/1e12:6.0f} | {td*1e6:9.1f} {fl/td/1e12:6.0f} | {tw*1e6:9.1f} {fl/tw/1e12:6.0f}   x{cnt}")
+    print(f"{name:34s} {fl/1e9:8.1f} | {tf*1e6:9.1f} {fl/tf/1e12:6.0f} | {td*1e6:9.1f} {fl/td/1e12:6.0f} | {tw*1e6:9.1f} {fl/tw/1e12:6.0f}   x{cnt}{extra}")
 print("totals per step (ms): " + ", ".join(f"{k} {v*1e3:.2f}" for k, v in tot.items()))
