@@ -58,6 +58,12 @@ struct ConvParams {
   // (ReLU).  With oscale = gamma / sqrt(running_var + eps) and bias = beta - running_mean * oscale this is an inference
   // BatchNorm folded into the convolution (fprop only; null = 1).
   const float* oscale;
+  // dgrad only: a second, COMPACT addend [sN, a2_H, a2_W, a2_cs]: output pixel (h, w) gets addend2[img][h / 2][w / 2] added
+  // when h and w are both even, nothing otherwise - the gradient of a 1x1 / stride-2 convolution (a ResNet downsample
+  // branch) without its three quarters of zeros.  Only the pre-split fp32 kernel (conv_x6p.hip) implements it; every
+  // other path makes dpa_conv_igemm return 4 before anything is launched (the caller then adds a dense tensor).
+  const void* addend2;
+  int a2_H, a2_W, a2_cs, a2_pad;
   int sN, sH, sW, sC, s_cs, s_co;
   int dH, dW, dC, d_cs, d_co;
   int R, S, sh, sw, ph, pw;

@@ -812,6 +812,7 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
   if (p.sC % VEC || p.s_cs % VEC || p.s_co % VEC || p.dC % VEC || p.d_cs % VEC || p.d_co % VEC) return 1;
   if ((size_t)p.sN * p.sH * p.sW >= 0x7fffffffull || (size_t)p.sN * p.dH * p.dW >= 0x7fffffffull) return 2;
   if (!dgrad) {
+    if (p.addend2) return 4;
     p.cls_h0 = p.cls_w0 = 0; p.cls_nh = p.dH; p.cls_nw = p.dW;
     p.base_y = p.base_x = 0; p.tap_r0 = p.tap_s0 = 0; p.nR = p.R; p.nS = p.S;
     p.M = p.sN * p.dH * p.dW;
@@ -820,21 +821,37 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
     return 0;
   }
   // dgrad: one dense sub-problem per (a, b) parity class; a stride-s conv costs 1x the fprop work instead of s^2 x
+  auto make_class = [&](int a, int b, ConvParams& q) -> bool {      // false: the class has no pixels
+    q = p;
+    q.cls_h0 = ((a - p.ph) % p.sh + p.sh) % p.sh;
+    q.cls_w0 = ((b - p.pw) % p.sw + p.sw) % p.sw;
+    q.cls_nh = q.cls_h0 < p.dH ? (p.dH - q.cls_h0 + p.sh - 1) / p.sh : 0;
+    q.cls_nw = q.cls_w0 < p.dW ? (p.dW - q.cls_w0 + p.sw - 1) / p.sw : 0;
+    if (q.cls_nh == 0 || q.cls_nw == 0) return false;
+    q.tap_r0 = a; q.tap_s0 = b;
+    q.nR = a < p.R ? (p.R - a + p.sh - 1) / p.sh : 0;
+    q.nS = b < p.S ? (p.S - b + p.sw - 1) / p.sw : 0;
+    q.base_y = (q.cls_h0 + p.ph - a) / p.sh;
+    q.base_x = (q.cls_w0 + p.pw - b) / p.sw;
+    q.M = p.sN * q.cls_nh * q.cls_nw;
+    q.Kg = q.nR * q.nS * p.sC;          // 0 taps: the kernel only runs its epilogue (zeros + addend)
+    return true;
+  };
+  if (p.addend2) {
+    // compact addend: only conv_x6p.hip's epilogues know it.  Dry run over the classes BEFORE anything is launched.
+    if (sizeof(T) != 4 || !fp32_x6() || p.addend || p.a2_cs % 4 || p.a2_H != (p.dH + 1) / 2 || p.a2_W != (p.dW + 1) / 2) return 4;
+    for (int a = 0; a < p.sh; ++a)
+      for (int b = 0; b < p.sw; ++b) {
+        ConvParams q;
+        if (!make_class(a, b, q)) continue;
+        q.m_off = 0; q.stats_row0 = 0;
+        if (q.Kg == 0 || !dpa_x6p_eligible(q)) return 4;
+      }
+  }
   for (int a = 0; a < p.sh; ++a)
     for (int b = 0; b < p.sw; ++b) {
-      ConvParams q = p;
-      q.cls_h0 = ((a - p.ph) % p.sh + p.sh) % p.sh;
-      q.cls_w0 = ((b - p.pw) % p.sw + p.sw) % p.sw;
-      q.cls_nh = q.cls_h0 < p.dH ? (p.dH - q.cls_h0 + p.sh - 1) / p.sh : 0;
-      q.cls_nw = q.cls_w0 < p.dW ? (p.dW - q.cls_w0 + p.sw - 1) / p.sw : 0;
-      if (q.cls_nh == 0 || q.cls_nw == 0) continue;
-      q.tap_r0 = a; q.tap_s0 = b;
-      q.nR = a < p.R ? (p.R - a + p.sh - 1) / p.sh : 0;
-      q.nS = b < p.S ? (p.S - b + p.sw - 1) / p.sw : 0;
-      q.base_y = (q.cls_h0 + p.ph - a) / p.sh;
-      q.base_x = (q.cls_w0 + p.pw - b) / p.sw;
-      q.M = p.sN * q.cls_nh * q.cls_nw;
-      q.Kg = q.nR * q.nS * p.sC;          // 0 taps: the kernel only runs its epilogue (zeros + addend)
+      ConvParams q;
+      if (!make_class(a, b, q)) continue;
       // ... and when the addend IS the destination (in-place accumulation into an existing gradient) a class without
       // taps leaves its pixels unchanged: nothing to launch (3 of the 4 classes of a 1x1 stride-2 downsample conv)
       if (q.Kg == 0 && p.addend == p.dst) {

@@ -287,6 +287,20 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
   // per wave and the fused reduction cost more than the kernel it replaced.
   // plain variant (no fused reduction): one row group at a time - fewer live registers, and measurably faster on the
   // memory-bound 1x1 layers than the two-phase variant below (56x56 64->256 fprop: 1137 vs 1355 us)
+  // compact addend (dgrad, p.addend2): the value for GEMM row m, columns col .. col + 3, or zeros for pixels with an odd
+  // coordinate.  (img, hi, wi) of the full gradient tensor from the class row, as in the pixel map below.
+  const float* __restrict__ addend2 = reinterpret_cast<const float*>(p.addend2);
+  auto compact_addend = [&](int m, int col) __attribute__((always_inline)) {
+    const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+    const int jx = m - (int)t1 * p.cls_nw;
+    const uint32_t img = fd_div(t1, p.fd_nH);
+    const int iy = (int)t1 - (int)img * p.cls_nh;
+    const int hi = p.cls_h0 + p.sh * iy, wi = p.cls_w0 + p.sw * jx;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (((hi | wi) & 1) == 0)
+      a = *reinterpret_cast<const float4*>(addend2 + (((size_t)img * p.a2_H + (hi >> 1)) * p.a2_W + (wi >> 1)) * (size_t)p.a2_cs + col);
+    return a;
+  };
   auto store_rows_plain = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < 16; rr += RPI) {
@@ -308,6 +322,9 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
         if (addend) {
           const float4 a = *reinterpret_cast<const float4*>(addend + off);
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if constexpr (DGRAD) {
+          if (addend2) { const float4 a = compact_addend(m, col); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(dst + off) = v;
@@ -340,6 +357,9 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
       pix[g] = pixel;
       off[g] = pixel * (size_t)p.d_cs + (size_t)(p.d_co + c_ok);
       if (addend) av[g] = *reinterpret_cast<const float4*>(addend + off[g]);
+      if constexpr (DGRAD) {        // (never together with a dense addend: conv_igemm.hip launch_conv)
+        if (addend2) av[g] = ok[g] ? compact_addend(m, col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (fuse) {
         xv[g] = *reinterpret_cast<const float4*>(bx + pixel * (size_t)p.bnr_cs + c_ok);
         if (by) yv[g] = *reinterpret_cast<const float4*>(by + pixel * (size_t)p.bnr_y_cs + c_ok);
@@ -350,7 +370,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
       const int r = g * RPI + lane / LPR;
       float4 v = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc]);
       if (ok[g]) {
-        if (addend) { v.x += av[g].x; v.y += av[g].y; v.z += av[g].z; v.w += av[g].w; }
+        if (addend || (DGRAD && addend2)) { v.x += av[g].x; v.y += av[g].y; v.z += av[g].z; v.w += av[g].w; }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (fuse) {
           float a4[4] = {v.x, v.y, v.z, v.w};

@@ -272,7 +272,7 @@ bool dpa_x6s_eligible(const ConvParams& p) {
   // (a data gradient with the fused BatchNorm-backward reduction stays on conv_x6p.hip: its epilogue reads the BatchNorm's
   // input and output besides the addend - 14 GB per call on 56x56 x 256 channels at batch 1024 - and runs at 90 % of the
   // memory roofline there)
-  if (!linear || !p.wgt3 || p.sC != 64 || p.Kg != 64 || p.no_uni || p.oscale || p.splitK > 1 || p.bnr_x) return false;
+  if (!linear || !p.wgt3 || p.sC != 64 || p.Kg != 64 || p.no_uni || p.oscale || p.splitK > 1 || p.bnr_x || p.addend2) return false;
   if (!(p.dC == 64 || p.dC % 128 == 0)) return false;
   if (p.stats && p.addend) return false;      // (no layer of the zoo asks for both; the variant would spill registers)
   if ((p.s_cs | p.s_co) & 3) return false;

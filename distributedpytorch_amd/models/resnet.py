@@ -44,6 +44,7 @@ class BasicBlock:
         reduction of the layer that produced x (ConvBNAct: last_use); conv2 is the only reader of conv1's output."""
         if self.down is not None and _DOWN_LAST and sole_consumer and getattr(x, "bn_src", None) is not None:
             out = self.c1(ctx, x, relu=True, last_use=True)       # see _DOWN_LAST
+            x.compact_ok = True     # conv1's dgrad is the next (and last) contribution to x.grad after the downsample's
             identity = self.down(ctx, x, relu=False)
             return self.c2(ctx, out, relu=True, residual=identity, last_use=True)
         # the downsample branch runs FIRST so that, in the reversed backward order, its dgrad comes after conv1's and
@@ -68,6 +69,7 @@ class Bottleneck:
         if self.down is not None and _DOWN_LAST and sole_consumer and getattr(x, "bn_src", None) is not None:
             out = self.c1(ctx, x, relu=True, last_use=True)       # see _DOWN_LAST
             out = self.c2(ctx, out, relu=True, last_use=True)
+            x.compact_ok = True     # conv1's dgrad is the next (and last) contribution to x.grad after the downsample's
             identity = self.down(ctx, x, relu=False)
             return self.c3(ctx, out, relu=True, residual=identity, last_use=True)
         identity = x if self.down is None else self.down(ctx, x, relu=False)      # first: see BasicBlock

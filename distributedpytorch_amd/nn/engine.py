@@ -39,7 +39,7 @@ def input_pad(c: int, dtype) -> int:
 
 class Act:
     """An NHWC activation (possibly a channel slice of a wider buffer) plus its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab")
+    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = False):
         self.data = data
@@ -51,6 +51,12 @@ class Act:
         # written by the dgrad that completed this activation's gradient (which it also masked)
         self.bn_src = None
         self.bn_slab: Optional[torch.Tensor] = None
+        # compact_ok: the caller promises that the NEXT contribution to this gradient after a 1x1 / stride-2 convolution's
+        # is a Conv2d dgrad (models/resnet.py, blocks with a downsample branch); that convolution may then leave its
+        # gradient in grad_compact = (tensor [N, H/2, W/2, C], the layer) instead of a full-resolution tensor that is
+        # three quarters zeros (nn/layers.py: Conv2d._dgrad)
+        self.compact_ok = False
+        self.grad_compact = None
 
     @property
     def shape(self):

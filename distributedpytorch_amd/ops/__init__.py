@@ -45,6 +45,7 @@ def _make(name):
 for _n in _TENSOR_OPS:
     globals()[_n] = _make(_n)
 
+CompactAddendUnsupported = ref_ops.CompactAddendUnsupported
 out_size = ref_ops.out_size
 pool_out_size = ref_ops.pool_out_size
 

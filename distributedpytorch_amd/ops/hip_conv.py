@@ -12,6 +12,7 @@ import torch
 
 from . import native
 from .native import ConvParams, WgradParams, VP
+from .ref_ops import CompactAddendUnsupported   # noqa: F401  (conv_dgrad(addend2=...) on a launch that cannot take it)
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -85,9 +86,12 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     return y
 
 
-def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, addend2=None):
     """dx = conv_transpose(dy, w).  wt is the filter transposed to [Cin, kh, kw, Cout] (reduction-contiguous).
     addend (same geometry as dx) is added in the epilogue (gradient accumulation for fan-out).
+    addend2: a COMPACT second gradient [N, ceil(H / 2), ceil(W / 2), C], contiguous - the gradient of a 1x1 / stride-2
+    convolution over the same input without its zeros: added to the pixels with even coordinates.  Only the pre-split
+    fp32 kernel implements it; otherwise CompactAddendUnsupported is raised and nothing has been launched.
     bn_reduce = (x, y, mean, invstd, mask_scale, mask_shift, slab): dx is the COMPLETE gradient w.r.t. the output of a
     BatchNorm(+ReLU) with input x; the epilogue masks the values it stores (y > 0, or mask_scale * x + mask_shift > 0)
     and writes the per-tile partial sums (sum dz, sum dz * xhat) into slab [rows >= ceil(M / 64), 2, C].
@@ -109,6 +113,11 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
     assert wt.is_contiguous() and wt.shape[0] == p.dC and wt.shape[3] == p.sC
     if addend is not None:
         assert addend.stride() == dx.stride()
+    if addend2 is not None:
+        assert addend is None and addend2.is_contiguous() and addend2.dtype == dx.dtype and addend2.dim() == 4
+        assert tuple(addend2.shape) == (dx.shape[0], (dx.shape[1] + 1) // 2, (dx.shape[2] + 1) // 2, dx.shape[3])
+        p.addend2 = VP(addend2.data_ptr())
+        p.a2_H, p.a2_W, p.a2_cs = addend2.shape[1], addend2.shape[2], addend2.shape[3]
     if bn_reduce is not None:
         x, y, mean, invstd, mscale, mshift, slab = bn_reduce
         assert p.R >= sh and p.S >= sw, "fused BN reduction: the dgrad has to write every pixel"
@@ -122,6 +131,8 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
         p.bnr_mscale, p.bnr_mshift = native.ptr(mscale), native.ptr(mshift)
         p.bnr_slab = VP(slab.data_ptr())
     rc = lib.dpa_conv_igemm(ctypes.byref(p), _DT[dy.dtype], 1, native.stream_ptr())
+    if rc == 4 and addend2 is not None:
+        raise CompactAddendUnsupported("this launch does not take the pre-split fp32 kernel")
     if rc:
         raise RuntimeError(f"dpa_conv_igemm(dgrad) rejected geometry rc={rc}")
     return int(p.stats_rows_used) if bn_reduce is not None else 0

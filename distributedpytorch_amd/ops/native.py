@@ -35,6 +35,7 @@ class ConvParams(ctypes.Structure):
         ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP), ("stats_shift", VP), ("wgt3", VP), ("wgt3_plane", I64),
         ("bnr_x", VP), ("bnr_y", VP), ("bnr_mean", VP), ("bnr_invstd", VP), ("bnr_mscale", VP), ("bnr_mshift", VP), ("bnr_slab", VP),
         ("bnr_cs", I32), ("bnr_y_cs", I32), ("bnr_row0", I32), ("bnr_pad", I32), ("oscale", VP),
+        ("addend2", VP), ("a2_H", I32), ("a2_W", I32), ("a2_cs", I32), ("a2_pad", I32),
         ("sN", I32), ("sH", I32), ("sW", I32), ("sC", I32), ("s_cs", I32), ("s_co", I32),
         ("dH", I32), ("dW", I32), ("dC", I32), ("d_cs", I32), ("d_co", I32),
         ("R", I32), ("S", I32), ("sh", I32), ("sw", I32), ("ph", I32), ("pw", I32),

@@ -52,7 +52,11 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     return y
 
 
-def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
+class CompactAddendUnsupported(RuntimeError):
+    """conv_dgrad(addend2=...) on a launch that does not go to the pre-split fp32 kernel: nothing was launched."""
+
+
+def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, addend2=None):
     # wt: [Cin, kh, kw, Cout]  -> torch weight [Cout, Cin, kh, kw]
     w = wt.permute(3, 0, 1, 2).float()
     n, h, wd, c = dx.shape
@@ -60,6 +64,9 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None):
     g = _nhwc(g)
     if addend is not None:
         g = g + addend.float()
+    if addend2 is not None:         # compact gradient of a 1x1 / stride-2 convolution over the same input
+        g = g.clone()
+        g[:, ::2, ::2, :] += addend2.float()
     if bn_reduce is not None:       # fused BatchNorm-backward reduction (csrc/hip/conv_common.h: BnReduceLane)
         x, y, mean, invstd, mscale, mshift, slab = bn_reduce
         if y is not None:

@@ -468,6 +468,88 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
         gmax = max(g.norm().item() for g in out[0][2].values())
         worst = max((out[1][2][k] - g).norm().item() / gmax for k, g in out[0][2].items())
         assert 1 - cos < 2e-3 and worst < 0.1, (1 - cos, worst)
+        # the downsample blocks' compact gradients (nn/layers.py: Conv2d._dgrad) against full-resolution ones: same bits
+        from distributedpytorch_amd.nn import layers
+        keep = layers._COMPACT_DOWN
+        try:
+            res = {}
+            for compact in (True, False):
+                layers._COMPACT_DOWN = compact
+                torch.manual_seed(5)
+                net, _ = get_model("resnet50", 10, device="cuda", dtype=torch.float32)
+                made = []
+                orig = layers.ops.conv_dgrad
+                layers.ops.conv_dgrad = lambda *a, **kw: (made.append("addend2" in kw and kw["addend2"] is not None), orig(*a, **kw))[1]
+                try:
+                    _, loss, _ = framework_step(net, x, y)
+                finally:
+                    layers.ops.conv_dgrad = orig
+                res[compact] = (loss, grads_by_name(net), sum(made))
+            assert res[True][2] == 3 and res[False][2] == 0      # layer2.0, layer3.0, layer4.0 took a compact addend
+            assert res[True][0] == res[False][0]
+            for k, gk in res[False][1].items():
+                assert torch.equal(res[True][1][k], gk), k
+        finally:
+            layers._COMPACT_DOWN = keep
     finally:
         lib.dpa_x6s_knob(1, 1)
+        set_fp32_mode(prev)
+
+
+# (N, H, W, C = channels of dx, K = channels of dy, k, stride, pad) of the dgrad that TAKES the compact addend
+COMPACT_SHAPES = [
+    (4, 28, 28, 256, 128, 1, 1, 0),     # bottleneck conv1: 1x1, stride 1 (the division-free row -> pixel path)
+    (3, 30, 30, 64, 128, 3, 2, 1),      # basic-block conv1: 3x3, stride 2, four parity classes
+    (2, 17, 13, 128, 64, 3, 1, 1),      # odd map sizes: the compact tensor is ceil(H / 2) x ceil(W / 2)
+]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("shape", COMPACT_SHAPES)
+def test_conv_dgrad_compact_addend(shape, fused, x6p_variant):
+    """conv_dgrad(addend2=G): the compact gradient of a 1x1 / stride-2 convolution over the same input, added to the pixels
+    with even coordinates in the epilogue of the pre-split fp32 kernel - against the dense addend it replaces (zeros with G
+    at the even pixels): same bits, with and without the fused BatchNorm-backward reduction; a launch that cannot take
+    it raises before anything runs."""
+    from distributedpytorch_amd.ops import hip_conv, native
+    from distributedpytorch_amd.ops.native import set_fp32_mode
+    N, H, W, C, K, k, s, pd = shape
+    g = torch.Generator(device="cuda").manual_seed(31)
+    Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
+    dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g)
+    wt = torch.randn(C, k, k, K, device="cuda", generator=g) * (k * k * K) ** -0.5
+    G = torch.randn(N, (H + 1) // 2, (W + 1) // 2, C, device="cuda", generator=g)
+    z = torch.randn(N, H, W, C, device="cuda", generator=g)
+    y = torch.randn(N, H, W, C, device="cuda", generator=g)
+    mean = torch.randn(C, device="cuda", generator=g) * 0.3
+    invstd = torch.rand(C, device="cuda", generator=g) + 0.5
+    lib = native.hip_lib()
+    prev, prev_tiles = set_fp32_mode("x6"), lib.dpa_x6p_min_tiles(1)
+    try:
+        wt3 = hip_conv.split3_planes(wt, torch.empty(3 * wt.numel(), device="cuda", dtype=torch.bfloat16))
+        rows = hip_conv.bn_reduce_rows(N * H * W, (s, s))
+
+        def run(**kw):
+            dx = torch.full((N, H, W, C), float("nan"), device="cuda")
+            slab = torch.full((rows, 2, C), float("nan"), device="cuda")
+            if "dense" in kw:
+                dx.copy_(kw["dense"])
+                kw = dict(addend=dx)
+            used = hip_conv.conv_dgrad(dy, wt, dx, (s, s), (pd, pd), wt3=wt3,
+                                       bn_reduce=(z, y, mean, invstd, None, None, slab) if fused else None, **kw)
+            return dx, slab[:used].clone()
+        dense = torch.zeros(N, H, W, C, device="cuda")
+        dense[:, ::2, ::2, :] = G
+        want, want_slab = run(dense=dense)
+        got, got_slab = run(addend2=G)
+        assert torch.equal(got, want) and torch.equal(got_slab, want_slab)
+        # a launch that stays on the general kernel (exact fp32 arithmetic) must refuse, and must not have touched dx
+        set_fp32_mode("exact")
+        dx = torch.full((N, H, W, C), 7.0, device="cuda")
+        with pytest.raises(hip_conv.CompactAddendUnsupported):
+            hip_conv.conv_dgrad(dy, wt, dx, (s, s), (pd, pd), addend2=G)
+        torch.cuda.synchronize()
+        assert (dx == 7.0).all()
+    finally:
+        lib.dpa_x6p_min_tiles(prev_tiles)
         set_fp32_mode(prev)
