@@ -180,8 +180,18 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, int x_cs, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int r_cs,
                                                        T* __restrict__ y, int y_cs, long long M, int C, int relu,
-                                                       int rowsPerBlock) {
+                                                       int rowsPerBlock, uint32_t* __restrict__ bits) {
+  // bits (or null): [M][C / 32] words, bit b of word w = (y[row][32 w + b] > 0) - the ReLU mask a later fused dgrad
+  // epilogue reads instead of y itself (1 / 32 of the bytes).  A thread owns VEC channels; the 32 / VEC adjacent lanes of a
+  // word OR their bits together with shuffles (C % 32 == 0: a word's lanes are always active together).
   constexpr int VEC = 16 / sizeof(T);
+  constexpr int LPW = 32 / VEC;                    // lanes per mask word
+  auto put_bits = [&](long long m, int c, uint32_t mine) __attribute__((always_inline)) {
+    uint32_t w = mine << ((c & 31));
+#pragma unroll
+    for (int o = 1; o < LPW; o <<= 1) w |= (uint32_t)__shfl_xor((int)w, o, 64);
+    if (((c / VEC) & (LPW - 1)) == 0) bits[m * (C >> 5) + (c >> 5)] = w;
+  };
   const int cpr = C / VEC;
   const int colsPerPass = cpr < 256 ? cpr : 256;
   const int rowLanes = 256 / colsPerPass;
@@ -214,28 +224,34 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         Vec16<T> o;
+        uint32_t pos = 0;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float f = v[u].get(e) * sc[e] + sh[e];
           if (res) f += rv[u].get(e);
           if (relu) f = fmaxf(f, 0.f);
           o.set(e, f);
+          pos |= (o.get(e) > 0.f ? 1u : 0u) << e;      // (of the value as stored)
         }
         o.store(y + (m + (long long)u * rowLanes) * y_cs + c);
+        if (bits) put_bits(m + (long long)u * rowLanes, c, pos);
       }
     }
     for (; m < r1; m += rowLanes) {
       Vec16<T> v; v.load(x + m * x_cs + c);
       Vec16<T> rv; if (res) rv.load(res + m * r_cs + c);
       Vec16<T> o;
+      uint32_t pos = 0;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float f = v.get(e) * sc[e] + sh[e];
         if (res) f += rv.get(e);
         if (relu) f = fmaxf(f, 0.f);
         o.set(e, f);
+        pos |= (o.get(e) > 0.f ? 1u : 0u) << e;
       }
       o.store(y + m * y_cs + c);
+      if (bits) put_bits(m, c, pos);
     }
   }
 }
@@ -465,12 +481,13 @@ DPA_API int dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, con
   return dpa_launch_rc();
 }
 DPA_API int dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
-                          int y_cs, long long M, int C, int relu, int dtype, hipStream_t s) {
+                          int y_cs, long long M, int C, int relu, int dtype, hipStream_t s, void* bits) {
+  if (bits && (C % 32)) return 1;
   int nb; const int rpb = ew_rows_per_block(M, C, dtype == 1 ? 2 : 4, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
-                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb);
+                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb, (uint32_t*)bits);
   else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
-                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu, rpb);
+                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu, rpb, (uint32_t*)bits);
   return dpa_launch_rc();
 }
 // slab: >= dpa_bn_slab_rows(M)*2*C floats; scratch >= ROWS_L2*2*C; sums: 2*C floats; coef: 3*C floats (for bn_bwd_dx)

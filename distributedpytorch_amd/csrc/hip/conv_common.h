@@ -51,6 +51,8 @@ struct ConvParams {
   const float* bnr_mscale;   // [dC] or null
   const float* bnr_mshift;   // [dC] or null
   float* bnr_slab;
+  const void* bnr_bits;      // or null: the ReLU mask as bits, [pixels][dC / 32] words (bn_apply_kernel) - kernels that know it
+                             // (conv_x6p.hip) read it INSTEAD of bnr_y: 1 / 32 of the bytes; the others use bnr_y
   int bnr_cs, bnr_y_cs;
   int bnr_row0;              // first slab row of this parity class (host)
   int bnr_pad;

@@ -338,9 +338,12 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     size_t off[NG], pix[NG];
     bool ok[NG];
     float4 av[NG], xv[NG], yv[NG];
+    uint32_t mw[NG];
     const bool fuse = DGRAD && p.bnr_x != nullptr;
     const float* __restrict__ bx = reinterpret_cast<const float*>(p.bnr_x);
-    const float* __restrict__ by = reinterpret_cast<const float*>(p.bnr_y);
+    const uint32_t* __restrict__ bits = reinterpret_cast<const uint32_t*>(p.bnr_bits);
+    // (the ReLU mask as bits when the producer made them: one word per 32 channels instead of 128 bytes of y)
+    const float* __restrict__ by = bits ? nullptr : reinterpret_cast<const float*>(p.bnr_y);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int m = m0 + wave * WROWS + i * 16 + g * RPI + lane / LPR;
@@ -363,6 +366,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
       if (fuse) {
         xv[g] = *reinterpret_cast<const float4*>(bx + pixel * (size_t)p.bnr_cs + c_ok);
         if (by) yv[g] = *reinterpret_cast<const float4*>(by + pixel * (size_t)p.bnr_y_cs + c_ok);
+        if (bits) mw[g] = bits[pixel * (size_t)(p.dC >> 5) + (c_ok >> 5)];
       }
     }
 #pragma unroll
@@ -375,8 +379,13 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
         if (fuse) {
           float a4[4] = {v.x, v.y, v.z, v.w};
           const float x4[4] = {xv[g].x, xv[g].y, xv[g].z, xv[g].w};
-          const float y4[4] = {yv[g].x, yv[g].y, yv[g].z, yv[g].w};
-          bnr.visit_loaded(by != nullptr, x4, y4, a4);
+          float y4[4] = {yv[g].x, yv[g].y, yv[g].z, yv[g].w};
+          if (bits) {
+            const uint32_t nib = mw[g] >> (col & 31);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y4[e] = (nib >> e) & 1u ? 1.f : 0.f;
+          }
+          bnr.visit_loaded(by != nullptr || bits != nullptr, x4, y4, a4);
           v = make_float4(a4[0], a4[1], a4[2], a4[3]);
         }
         *reinterpret_cast<float4*>(dst + off[g]) = v;

@@ -28,6 +28,8 @@ _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
 # DPA_COMPACT_DOWN=0: the data gradient of a 1x1 / stride-2 downsample convolution is always a full-resolution tensor
 # (A/B switch; see Conv2d._dgrad)
 _COMPACT_DOWN = os.environ.get("DPA_COMPACT_DOWN", "1") != "0"
+# DPA_RELU_BITS=0: no bit masks next to BatchNorm + residual + ReLU outputs; the fused dgrad epilogue reads y (A/B switch)
+_RELU_BITS = os.environ.get("DPA_RELU_BITS", "1") != "0"
 
 
 def _pair(v):
@@ -221,7 +223,8 @@ class Conv2d:
         # 91.6 ms; it was +2.5 ms before the finalize kernels were rewritten).  DPA_FUSE_BN_BWD=fp32 keeps bf16 unfused.
         if x.data.dtype != torch.float32 and os.environ.get("DPA_FUSE_BN_BWD") == "fp32":
             return None
-        bn, z, mask_from_x = x.bn_src
+        bn, z, mask_from_x = x.bn_src[:3]
+        bits = x.bn_src[3] if len(x.bn_src) > 3 else None
         if z.shape != x.data.shape:
             return None
         a = bn.aux(ctx.device)
@@ -230,7 +233,7 @@ class Conv2d:
         slab = ctx.empty((rows, 2, c), dtype=torch.float32)
         if mask_from_x:
             return (z, None, a[0], a[1], a[2], a[3], slab)
-        return (z, x.data, a[0], a[1], None, None, slab)
+        return (z, x.data, a[0], a[1], None, None, slab) + ((bits,) if bits is not None else ())
 
     def _dgrad(self, ctx, x, dy, last_use=False):
         w = self.store.cview(self.w)
@@ -408,13 +411,20 @@ class ConvBNAct:
         a = bn.coeffs(ctx, slab, m)
         if out is None:
             out = ctx.empty((n, ho, wo, cp))
-        ops.bn_apply(z, a[2], a[3], out, residual=None if residual is None else residual.data, relu=relu)
         needs = x.needs_grad or conv.trainable or bn.trainable or (residual is not None and residual.needs_grad)
+        # BatchNorm + residual + ReLU in training: the ReLU mask also as bits (1 / 32 of y's bytes) for the dgrad that
+        # will complete this activation's gradient and mask it in its epilogue (Conv2d._bn_fusion)
+        bits = None
+        if (_RELU_BITS and relu and residual is not None and ctx.training and ctx.grad_enabled and needs and _FUSE_BN_BWD
+                and ctx.cuda and out.dtype == torch.float32 and cp % 32 == 0 and out.is_contiguous()):
+            bits = ctx.empty((m, cp // 32), dtype=torch.int32)
+        ops.bn_apply(z, a[2], a[3], out, residual=None if residual is None else residual.data, relu=relu, mask_bits=bits)
         y = Act(out, needs)
         if ctx.grad_enabled and needs:
             mask_from_x = relu and residual is None and ctx.training
             if relu and ctx.training:
-                y.bn_src = (bn, z, mask_from_x)      # a consumer's dgrad may do this BatchNorm's backward reduction
+                # a consumer's dgrad may do this BatchNorm's backward reduction
+                y.bn_src = (bn, z, mask_from_x) + ((bits,) if bits is not None else ())
 
             def bw():
                 dy = y.grad

@@ -92,7 +92,7 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
     addend2: a COMPACT second gradient [N, ceil(H / 2), ceil(W / 2), C], contiguous - the gradient of a 1x1 / stride-2
     convolution over the same input without its zeros: added to the pixels with even coordinates.  Only the pre-split
     fp32 kernel implements it; otherwise CompactAddendUnsupported is raised and nothing has been launched.
-    bn_reduce = (x, y, mean, invstd, mask_scale, mask_shift, slab): dx is the COMPLETE gradient w.r.t. the output of a
+    bn_reduce = (x, y, mean, invstd, mask_scale, mask_shift, slab[, bits]): dx is the COMPLETE gradient w.r.t. the output of a
     BatchNorm(+ReLU) with input x; the epilogue masks the values it stores (y > 0, or mask_scale * x + mask_shift > 0)
     and writes the per-tile partial sums (sum dz, sum dz * xhat) into slab [rows >= ceil(M / 64), 2, C].
     Returns the number of slab rows written (0 without bn_reduce)."""
@@ -119,7 +119,12 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
         p.addend2 = VP(addend2.data_ptr())
         p.a2_H, p.a2_W, p.a2_cs = addend2.shape[1], addend2.shape[2], addend2.shape[3]
     if bn_reduce is not None:
-        x, y, mean, invstd, mscale, mshift, slab = bn_reduce
+        x, y, mean, invstd, mscale, mshift, slab = bn_reduce[:7]
+        bits = bn_reduce[7] if len(bn_reduce) > 7 else None      # y's ReLU mask as bits (bn_apply(mask_bits=)): read instead of y
+        if bits is not None:                                      # by the kernels that know them
+            assert y is not None and dx.shape[3] % 32 == 0 and bits.dtype == torch.int32 and bits.is_contiguous() \
+                and bits.numel() == dx.shape[0] * dx.shape[1] * dx.shape[2] * (dx.shape[3] // 32)
+            p.bnr_bits = VP(bits.data_ptr())
         assert p.R >= sh and p.S >= sw, "fused BN reduction: the dgrad has to write every pixel"
         assert x.shape == dx.shape and x.dtype == dx.dtype and (y is None or (y.shape == dx.shape and y.dtype == dx.dtype))
         n_px = dx.shape[0] * dx.shape[1] * dx.shape[2]

@@ -68,7 +68,7 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
         g = g.clone()
         g[:, ::2, ::2, :] += addend2.float()
     if bn_reduce is not None:       # fused BatchNorm-backward reduction (csrc/hip/conv_common.h: BnReduceLane)
-        x, y, mean, invstd, mscale, mshift, slab = bn_reduce
+        x, y, mean, invstd, mscale, mshift, slab = bn_reduce[:7]      # (an eighth element: y's mask as bits, same mask)
         if y is not None:
             g = g * (y > 0)
         elif mscale is not None:
@@ -150,13 +150,18 @@ def bn_eval_coeffs(gamma, beta, rm, rv, eps, scale, shift):
     shift.copy_(b - rm * g * inv)
 
 
-def bn_apply(x, scale, shift, y, residual=None, relu=False):
+def bn_apply(x, scale, shift, y, residual=None, relu=False, mask_bits=None):
     out = x.float() * scale + shift
     if residual is not None:
         out = out + residual.float()
     if relu:
         out = out.clamp_min(0)
     y.copy_(out.to(y.dtype))
+    if mask_bits is not None:       # bit b of word w = (y[row, 32 w + b] > 0)
+        c = y.shape[-1]
+        pos = (y.reshape(-1, c // 32, 32) > 0).to(torch.int64)
+        words = (pos << torch.arange(32, dtype=torch.int64, device=y.device)).sum(-1)
+        mask_bits.copy_(torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).reshape(mask_bits.shape))
     return y
 
 

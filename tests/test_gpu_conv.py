@@ -295,7 +295,15 @@ BNR_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("mask", ["y", "x", "none"])
+def _pack_mask_bits(y):
+    """[..., C] -> int32 [rows, C / 32], bit b of word w = (y[row, 32 w + b] > 0) (the layout bn_apply(mask_bits=) writes)."""
+    c = y.shape[-1]
+    pos = (y.reshape(-1, c // 32, 32) > 0).to(torch.int64)
+    words = (pos << torch.arange(32, dtype=torch.int64, device=y.device)).sum(-1)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+
+
+@pytest.mark.parametrize("mask", ["y", "ybits", "x", "none"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", BNR_SHAPES)
 def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_variant):
@@ -307,6 +315,8 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
     if x6p_variant != "narrow" and not (dtype == torch.float32 and fp32_mode == "x6"):
         pytest.skip("the tile variants exist in the pre-split fp32 kernel only")
     N, H, W, C, K, k, s, pd = shape
+    if mask == "ybits" and C % 32:
+        pytest.skip("bit masks need a multiple of 32 channels")
     g = torch.Generator(device="cuda").manual_seed(99)
     Ho, Wo = hip_conv.out_size(H, k, s, pd), hip_conv.out_size(W, k, s, pd)
     dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g).to(dtype)
@@ -326,7 +336,7 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
         if use_addend:
             plain.copy_(addend)
         hip_conv.conv_dgrad(dy, wt, plain, (s, s), (pd, pd), addend=plain if use_addend else None, wt3=wt3)
-        if mask == "y":
+        if mask in ("y", "ybits"):
             keep = y > 0
         elif mask == "x":
             keep = (z.float() * msc + msh) > 0
@@ -339,8 +349,9 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
         if use_addend:
             fused.copy_(addend)
         used = hip_conv.conv_dgrad(dy, wt, fused, (s, s), (pd, pd), addend=fused if use_addend else None, wt3=wt3,
-                                   bn_reduce=(z, y if mask == "y" else None, mean, invstd,
-                                              msc if mask == "x" else None, msh if mask == "x" else None, slab))
+                                   bn_reduce=(z, y if mask in ("y", "ybits") else None, mean, invstd,
+                                              msc if mask == "x" else None, msh if mask == "x" else None, slab)
+                                   + ((_pack_mask_bits(y),) if mask == "ybits" else ()))
         assert 0 < used <= rows
         assert torch.equal(fused, want)                      # same arithmetic, masked
         got = slab[:used].double().sum(0)
@@ -468,29 +479,38 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
         gmax = max(g.norm().item() for g in out[0][2].values())
         worst = max((out[1][2][k] - g).norm().item() / gmax for k, g in out[0][2].items())
         assert 1 - cos < 2e-3 and worst < 0.1, (1 - cos, worst)
-        # the downsample blocks' compact gradients (nn/layers.py: Conv2d._dgrad) against full-resolution ones: same bits
+        # the downsample blocks' compact gradients (nn/layers.py: Conv2d._dgrad) against full-resolution ones, and the ReLU
+        # masks as bits (ConvBNAct) against the fused epilogues reading y itself: same bits in every gradient
         from distributedpytorch_amd.nn import layers
-        keep = layers._COMPACT_DOWN
+        keep = layers._COMPACT_DOWN, layers._RELU_BITS
         try:
             res = {}
-            for compact in (True, False):
-                layers._COMPACT_DOWN = compact
+            for compact, relu_bits in ((True, True), (False, True), (True, False)):
+                layers._COMPACT_DOWN, layers._RELU_BITS = compact, relu_bits
                 torch.manual_seed(5)
                 net, _ = get_model("resnet50", 10, device="cuda", dtype=torch.float32)
-                made = []
+                made, with_bits = [], []
                 orig = layers.ops.conv_dgrad
-                layers.ops.conv_dgrad = lambda *a, **kw: (made.append("addend2" in kw and kw["addend2"] is not None), orig(*a, **kw))[1]
+
+                def spy(*a, **kw):
+                    made.append(kw.get("addend2") is not None)
+                    with_bits.append(kw.get("bn_reduce") is not None and len(kw["bn_reduce"]) > 7)
+                    return orig(*a, **kw)
+                layers.ops.conv_dgrad = spy
                 try:
                     _, loss, _ = framework_step(net, x, y)
                 finally:
                     layers.ops.conv_dgrad = orig
-                res[compact] = (loss, grads_by_name(net), sum(made))
-            assert res[True][2] == 3 and res[False][2] == 0      # layer2.0, layer3.0, layer4.0 took a compact addend
-            assert res[True][0] == res[False][0]
-            for k, gk in res[False][1].items():
-                assert torch.equal(res[True][1][k], gk), k
+                res[(compact, relu_bits)] = (loss, grads_by_name(net), sum(made), sum(with_bits))
+            base = res[(True, True)]
+            assert base[2] == 3 and res[(False, True)][2] == 0       # layer2.0, layer3.0, layer4.0 took a compact addend
+            assert base[3] == 15 and res[(True, False)][3] == 0      # conv1 of every block after a residual ReLU read the bits
+            for other in ((False, True), (True, False)):
+                assert res[other][0] == base[0]
+                for k, gk in base[1].items():
+                    assert torch.equal(res[other][1][k], gk), (other, k)
         finally:
-            layers._COMPACT_DOWN = keep
+            layers._COMPACT_DOWN, layers._RELU_BITS = keep
     finally:
         lib.dpa_x6s_knob(1, 1)
         set_fp32_mode(prev)

@@ -368,3 +368,27 @@ def test_fused_bn_relu_maxpool_forward(shape, dtype):
     idx = torch.empty_like(ref_i)
     H.maxpool_fwd(z, y, idx, (k, k), (s, s), (pd, pd), scale=sc, shift=sh)
     assert torch.equal(y, ref_y) and torch.equal(idx, ref_i)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,c", [(1000, 64), (4099, 256), (77, 1024), (513, 2048), (300, 32)])
+def test_bn_apply_writes_the_relu_mask_as_bits(m, c, dtype):
+    """bn_apply(mask_bits=): bit b of word w of a row = (y[row, 32 w + b] > 0), for every channel-chunk / row-lane shape of
+    the kernel (a thread owns 4 or 8 channels; the lanes of a word combine their bits with shuffles)."""
+    from distributedpytorch_amd.ops import hip_ops
+    g = torch.Generator(device="cuda").manual_seed(m + c)
+    x = torch.randn(m, 1, 1, c, device="cuda", generator=g).to(dtype)
+    res = torch.randn(m, 1, 1, c, device="cuda", generator=g).to(dtype)
+    scale = torch.rand(c, device="cuda", generator=g) + 0.5
+    shift = torch.randn(c, device="cuda", generator=g) * 0.3
+    for residual in (res, None):
+        y = torch.empty_like(x)
+        bits = torch.full((m, c // 32), -1, device="cuda", dtype=torch.int32)
+        hip_ops.bn_apply(x, scale, shift, y, residual=residual, relu=True, mask_bits=bits)
+        y2 = torch.empty_like(x)
+        hip_ops.bn_apply(x, scale, shift, y2, residual=residual, relu=True)
+        assert torch.equal(y, y2)
+        pos = (y.reshape(m, c // 32, 32) > 0).to(torch.int64)
+        words = (pos << torch.arange(32, dtype=torch.int64, device="cuda")).sum(-1)
+        want = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+        assert torch.equal(bits, want)
