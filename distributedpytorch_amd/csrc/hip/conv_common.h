@@ -53,6 +53,15 @@ struct ConvParams {
   float* bnr_slab;
   const void* bnr_bits;      // or null: the ReLU mask as bits, [pixels][dC / 32] words (bn_apply_kernel) - kernels that know it
                              // (conv_x6p.hip) read it INSTEAD of bnr_y: 1 / 32 of the bytes; the others use bnr_y
+  // A SECOND BatchNorm whose output was added to the first one's before the ReLU (the downsample branch of a ResNet
+  // block): same gradient, same mask, so sum dz is shared and the epilogue only adds sum dz * xhat2 over its input
+  // bnr2_x: slab rows (sum dz, sum dz * xhat2) go to bnr2_slab.  Only conv_x6p.hip, and only together with bnr_bits
+  // (dpa_conv_igemm returns 5 before launching anything otherwise).
+  const void* bnr2_x;
+  const float* bnr2_mean;
+  const float* bnr2_invstd;
+  float* bnr2_slab;
+  int bnr2_cs, bnr2_pad;
   int bnr_cs, bnr_y_cs;
   int bnr_row0;              // first slab row of this parity class (host)
   int bnr_pad;

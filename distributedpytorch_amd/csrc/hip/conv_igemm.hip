@@ -813,6 +813,7 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
   if ((size_t)p.sN * p.sH * p.sW >= 0x7fffffffull || (size_t)p.sN * p.dH * p.dW >= 0x7fffffffull) return 2;
   if (!dgrad) {
     if (p.addend2) return 4;
+    if (p.bnr2_x) return 5;
     p.cls_h0 = p.cls_w0 = 0; p.cls_nh = p.dH; p.cls_nw = p.dW;
     p.base_y = p.base_x = 0; p.tap_r0 = p.tap_s0 = 0; p.nR = p.R; p.nS = p.S;
     p.M = p.sN * p.dH * p.dW;
@@ -837,15 +838,19 @@ static int launch_conv(ConvParams& p, int dgrad, hipStream_t s) {
     q.Kg = q.nR * q.nS * p.sC;          // 0 taps: the kernel only runs its epilogue (zeros + addend)
     return true;
   };
-  if (p.addend2) {
-    // compact addend: only conv_x6p.hip's epilogues know it.  Dry run over the classes BEFORE anything is launched.
-    if (sizeof(T) != 4 || !fp32_x6() || p.addend || p.a2_cs % 4 || p.a2_H != (p.dH + 1) / 2 || p.a2_W != (p.dW + 1) / 2) return 4;
+  if (p.addend2 || p.bnr2_x) {
+    // compact addend, second BatchNorm reduction: only conv_x6p.hip's epilogues know them.  Dry run over the classes BEFORE
+    // anything is launched.
+    const int refuse = p.addend2 ? 4 : 5;
+    if (sizeof(T) != 4 || !fp32_x6()) return refuse;
+    if (p.addend2 && (p.addend || p.a2_cs % 4 || p.a2_H != (p.dH + 1) / 2 || p.a2_W != (p.dW + 1) / 2)) return 4;
+    if (p.bnr2_x && (!p.bnr_x || !p.bnr_bits || p.bnr2_cs % 4)) return 5;
     for (int a = 0; a < p.sh; ++a)
       for (int b = 0; b < p.sw; ++b) {
         ConvParams q;
         if (!make_class(a, b, q)) continue;
         q.m_off = 0; q.stats_row0 = 0;
-        if (q.Kg == 0 || !dpa_x6p_eligible(q)) return 4;
+        if (q.Kg == 0 || !dpa_x6p_eligible(q)) return refuse;
       }
   }
   for (int a = 0; a < p.sh; ++a)

@@ -281,6 +281,8 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 
   BnReduceLane<float, 4> bnr;                  // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
   if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + (lane % LPR) * 4); }
+  // the second BatchNorm of the same sum (conv_common.h: bnr2_x): sum dz * xhat2 (constants loaded at the epilogue's start)
+  float q2[4] = {0.f, 0.f, 0.f, 0.f}, mu2[4] = {0.f, 0.f, 0.f, 0.f}, is2[4] = {0.f, 0.f, 0.f, 0.f};
   // 16 staged rows (block rows m0 + wave*WROWS + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map, fused BN reduce.
   // Two phases so that every global read of the 16 rows (addend, and for the fused BatchNorm reduction x and y) is in
   // flight before the first one is consumed: issued one row group at a time, their latency was exposed 16 / RPI times
@@ -344,6 +346,8 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     const uint32_t* __restrict__ bits = reinterpret_cast<const uint32_t*>(p.bnr_bits);
     // (the ReLU mask as bits when the producer made them: one word per 32 channels instead of 128 bytes of y)
     const float* __restrict__ by = bits ? nullptr : reinterpret_cast<const float*>(p.bnr_y);
+    // (the second BatchNorm's input: only with the bit mask - its values live in the registers y would take)
+    const float* __restrict__ bx2 = bits ? reinterpret_cast<const float*>(p.bnr2_x) : nullptr;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int m = m0 + wave * WROWS + i * 16 + g * RPI + lane / LPR;
@@ -367,6 +371,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
         xv[g] = *reinterpret_cast<const float4*>(bx + pixel * (size_t)p.bnr_cs + c_ok);
         if (by) yv[g] = *reinterpret_cast<const float4*>(by + pixel * (size_t)p.bnr_y_cs + c_ok);
         if (bits) mw[g] = bits[pixel * (size_t)(p.dC >> 5) + (c_ok >> 5)];
+        if (bx2) yv[g] = *reinterpret_cast<const float4*>(bx2 + pixel * (size_t)p.bnr2_cs + c_ok);
       }
     }
 #pragma unroll
@@ -380,12 +385,17 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
           float a4[4] = {v.x, v.y, v.z, v.w};
           const float x4[4] = {xv[g].x, xv[g].y, xv[g].z, xv[g].w};
           float y4[4] = {yv[g].x, yv[g].y, yv[g].z, yv[g].w};
+          const float z2[4] = {yv[g].x, yv[g].y, yv[g].z, yv[g].w};      // (the second BatchNorm's input when bx2)
           if (bits) {
             const uint32_t nib = mw[g] >> (col & 31);
 #pragma unroll
             for (int e = 0; e < 4; ++e) y4[e] = (nib >> e) & 1u ? 1.f : 0.f;
           }
           bnr.visit_loaded(by != nullptr || bits != nullptr, x4, y4, a4);
+          if (bx2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q2[e] += a4[e] * (z2[e] - mu2[e]) * is2[e];
+          }
           v = make_float4(a4[0], a4[1], a4[2], a4[3]);
         }
         *reinterpret_cast<float4*>(dst + off[g]) = v;
@@ -613,6 +623,15 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     __syncthreads();
 
     // ---- epilogue: acc[i][j][e] = D[row = wave*WROWS + i*16 + fq*4 + e][col = j*16 + fr] ---------------------------------
+    if constexpr (DGRAD) {
+      if (p.bnr2_x) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c2 = n0 + (lane % LPR) * 4 + e;
+          mu2[e] = c2 < p.dC ? p.bnr2_mean[c2] : 0.f; is2[e] = c2 < p.dC ? p.bnr2_invstd[c2] : 0.f;
+        }
+      }
+    }
     float csum[TN], csq[TN], bj[TN], cj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -681,6 +700,20 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
           }
         }
         write_stats(p.bnr_slab, p.bnr_row0 + p.stats_row0);
+        if (p.bnr2_x) {
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float s = bnr.s[e], q = q2[e];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            if (lane < LPR) {
+              red[(wave * 2 + 0) * BN + lane * 4 + e] = s;
+              red[(wave * 2 + 1) * BN + lane * 4 + e] = q;
+            }
+          }
+          write_stats(p.bnr2_slab, p.bnr_row0 + p.stats_row0);
+        }
       }
     }
   }

@@ -39,7 +39,7 @@ def input_pad(c: int, dtype) -> int:
 
 class Act:
     """An NHWC activation (possibly a channel slice of a wider buffer) plus its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact")
+    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact", "bn_lin", "bn_src2", "bn_slab2")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = False):
         self.data = data
@@ -57,6 +57,12 @@ class Act:
         # three quarters zeros (nn/layers.py: Conv2d._dgrad)
         self.compact_ok = False
         self.grad_compact = None
+        # a SECOND BatchNorm in the sum under this activation's ReLU (the downsample branch of a ResNet block):
+        # bn_lin = (bn, z) on the output of a BatchNorm without ReLU / residual; bn_src2 = the residual's bn_lin on the
+        # block output; bn_slab2 = its partial sums, written by the same dgrad epilogue as bn_slab (nn/layers.py)
+        self.bn_lin = None
+        self.bn_src2 = None
+        self.bn_slab2 = None
 
     @property
     def shape(self):

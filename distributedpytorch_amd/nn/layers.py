@@ -30,6 +30,8 @@ _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
 _COMPACT_DOWN = os.environ.get("DPA_COMPACT_DOWN", "1") != "0"
 # DPA_RELU_BITS=0: no bit masks next to BatchNorm + residual + ReLU outputs; the fused dgrad epilogue reads y (A/B switch)
 _RELU_BITS = os.environ.get("DPA_RELU_BITS", "1") != "0"
+# DPA_FUSE_BN2=0: the BatchNorm of a downsample branch always runs its own backward reduction (A/B switch; see ConvBNAct)
+_FUSE_BN2 = os.environ.get("DPA_FUSE_BN2", "1") != "0"
 
 
 def _pair(v):
@@ -91,6 +93,7 @@ class Conv2d:
         self._wt = None
         self._ev = None
         self._no_compact = False         # set when the dgrad after this layer's could not take a compact gradient
+        self._no_bn2 = False             # set when this layer's dgrad could not take a second BatchNorm reduction
         self._w3 = self._wt3 = None      # the filter / transposed filter as three bf16 planes (fp32 x6 fast path)
         self.last_stats_rows = 1
 
@@ -233,7 +236,24 @@ class Conv2d:
         slab = ctx.empty((rows, 2, c), dtype=torch.float32)
         if mask_from_x:
             return (z, None, a[0], a[1], a[2], a[3], slab)
-        return (z, x.data, a[0], a[1], None, None, slab) + ((bits,) if bits is not None else ())
+        fuse = (z, x.data, a[0], a[1], None, None, slab) + ((bits,) if bits is not None else ())
+        if bits is not None and x.bn_src2 is not None and _FUSE_BN2 and not self._no_bn2:
+            bn2, z2 = x.bn_src2
+            if z2.shape == x.data.shape:
+                a2 = bn2.aux(ctx.device)
+                fuse = fuse + ((z2, a2[0], a2[1], ctx.empty((rows, 2, c), dtype=torch.float32)),)
+        return fuse
+
+    def _conv_dgrad(self, *args, bn_reduce=None, **kw):
+        """ops.conv_dgrad; a launch that cannot take the second BatchNorm reduction (nothing was launched) is repeated
+        without it, and the layer stops asking.  Returns (slab rows, second reduction done)."""
+        if bn_reduce is not None and len(bn_reduce) > 8:
+            try:
+                return ops.conv_dgrad(*args, bn_reduce=bn_reduce, **kw), True
+            except ops.SecondBnUnsupported:
+                self._no_bn2 = True
+                bn_reduce = bn_reduce[:8]
+        return ops.conv_dgrad(*args, bn_reduce=bn_reduce, **kw), False
 
     def _dgrad(self, ctx, x, dy, last_use=False):
         w = self.store.cview(self.w)
@@ -274,23 +294,25 @@ class Conv2d:
             try:
                 if gemm:
                     raise ops.CompactAddendUnsupported("flattened whole-map convolution")
-                rows = ops.conv_dgrad(dy, wt, dx, stride, padding, wt3=wt3, bn_reduce=fuse, addend2=g)
+                rows, did2 = self._conv_dgrad(dy, wt, dx, stride, padding, wt3=wt3, bn_reduce=fuse, addend2=g)
             except ops.CompactAddendUnsupported:
                 # (this dgrad does not take the pre-split fp32 kernel: small problem, other arithmetic.  Nothing was
                 # launched; the compact gradient becomes the dense addend it replaces, and the layer stops making it)
                 src._no_compact = True
                 dx.zero_()
                 dx[:, ::2, ::2, :] = g
-                rows = ops.conv_dgrad(dy, wt, flat(dx), stride, padding, addend=flat(dx), wt3=wt3, bn_reduce=fuse)
+                rows, did2 = self._conv_dgrad(dy, wt, flat(dx), stride, padding, addend=flat(dx), wt3=wt3, bn_reduce=fuse)
             x.grad = dx
         elif x.grad is None:
             dx = x.grad_buf if x.grad_buf is not None else ctx.empty(tuple(x.data.shape))
-            rows = ops.conv_dgrad(dy, wt, flat(dx), stride, padding, wt3=wt3, bn_reduce=fuse)
+            rows, did2 = self._conv_dgrad(dy, wt, flat(dx), stride, padding, wt3=wt3, bn_reduce=fuse)
             x.grad = dx
         else:
-            rows = ops.conv_dgrad(dy, wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3, bn_reduce=fuse)
+            rows, did2 = self._conv_dgrad(dy, wt, flat(x.grad), stride, padding, addend=flat(x.grad), wt3=wt3, bn_reduce=fuse)
         if fuse is not None:
             x.bn_slab = fuse[6][:rows]
+            if did2:
+                x.bn_slab2 = fuse[8][3][:rows]
 
     def __call__(self, ctx: Context, x: Act, relu=False, out=None, last_use=False) -> Act:
         y = Act(self.forward_raw(ctx, x.data, out=out, relu=relu), x.needs_grad or self.trainable)
@@ -425,17 +447,25 @@ class ConvBNAct:
             if relu and ctx.training:
                 # a consumer's dgrad may do this BatchNorm's backward reduction
                 y.bn_src = (bn, z, mask_from_x) + ((bits,) if bits is not None else ())
+                # ... and the one of a second BatchNorm under the same ReLU (the residual came straight out of one)
+                if bits is not None and residual.bn_lin is not None and residual.needs_grad and residual.data.shape == out.shape:
+                    y.bn_src2 = residual.bn_lin
+            elif ctx.training and residual is None and not relu:
+                y.bn_lin = (bn, z)
 
             def bw():
                 dy = y.grad
                 y.grad = None
                 slab, y.bn_slab, y.bn_src = y.bn_slab, None, None
+                slab2, y.bn_slab2, y.bn_src2, y.bn_lin = y.bn_slab2, None, None, None
                 if slab is not None:       # dy arrived masked, its partial sums are in the slab
                     dz = _bn_backward_from_slab(bn, ctx, dy, z, z, slab, m)
                 else:
                     dz = bn.backward(ctx, dy, y.data if relu else None, z, z,   # dx overwrites z (dead after this)
                                      mask_from_x=mask_from_x)
                 if residual is not None and residual.needs_grad:
+                    if slab2 is not None and residual.grad is None:
+                        residual.bn_slab = slab2                             # the residual's BatchNorm: reduction done too
                     accumulate_grad(residual, dy)                            # dy now holds dy*(y>0)
                 conv.backward_raw(ctx, x, dz, last_use=last_use)
             ctx.tape.push(bw)

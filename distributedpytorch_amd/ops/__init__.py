@@ -46,6 +46,7 @@ for _n in _TENSOR_OPS:
     globals()[_n] = _make(_n)
 
 CompactAddendUnsupported = ref_ops.CompactAddendUnsupported
+SecondBnUnsupported = ref_ops.SecondBnUnsupported
 out_size = ref_ops.out_size
 pool_out_size = ref_ops.pool_out_size
 

@@ -12,7 +12,7 @@ import torch
 
 from . import native
 from .native import ConvParams, WgradParams, VP
-from .ref_ops import CompactAddendUnsupported   # noqa: F401  (conv_dgrad(addend2=...) on a launch that cannot take it)
+from .ref_ops import CompactAddendUnsupported, SecondBnUnsupported   # noqa: F401  (launches that cannot take these extras)
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -92,7 +92,7 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
     addend2: a COMPACT second gradient [N, ceil(H / 2), ceil(W / 2), C], contiguous - the gradient of a 1x1 / stride-2
     convolution over the same input without its zeros: added to the pixels with even coordinates.  Only the pre-split
     fp32 kernel implements it; otherwise CompactAddendUnsupported is raised and nothing has been launched.
-    bn_reduce = (x, y, mean, invstd, mask_scale, mask_shift, slab[, bits]): dx is the COMPLETE gradient w.r.t. the output of a
+    bn_reduce = (x, y, mean, invstd, mask_scale, mask_shift, slab[, bits[, (x2, mean2, invstd2, slab2)]]): dx is the COMPLETE gradient w.r.t. the output of a
     BatchNorm(+ReLU) with input x; the epilogue masks the values it stores (y > 0, or mask_scale * x + mask_shift > 0)
     and writes the per-tile partial sums (sum dz, sum dz * xhat) into slab [rows >= ceil(M / 64), 2, C].
     Returns the number of slab rows written (0 without bn_reduce)."""
@@ -125,6 +125,16 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
             assert y is not None and dx.shape[3] % 32 == 0 and bits.dtype == torch.int32 and bits.is_contiguous() \
                 and bits.numel() == dx.shape[0] * dx.shape[1] * dx.shape[2] * (dx.shape[3] // 32)
             p.bnr_bits = VP(bits.data_ptr())
+        # a second BatchNorm whose output was summed with the first one's before the ReLU (same gradient, same mask): its
+        # sum dz * xhat2 goes to slab2 [same rows, 2, C] (sum dz repeated in column 0).  Pre-split fp32 kernel + bits only:
+        # SecondBnUnsupported otherwise, and nothing has been launched
+        second = bn_reduce[8] if len(bn_reduce) > 8 else None
+        if second is not None:
+            x2, mean2, invstd2, slab2 = second
+            assert bits is not None and x2.shape == dx.shape and x2.dtype == dx.dtype and slab2.shape == slab.shape \
+                and slab2.dtype == torch.float32 and slab2.is_contiguous()
+            p.bnr2_x, p.bnr2_cs = VP(x2.data_ptr()), _check_nhwc(x2, "bn2 x")
+            p.bnr2_mean, p.bnr2_invstd, p.bnr2_slab = VP(mean2.data_ptr()), VP(invstd2.data_ptr()), VP(slab2.data_ptr())
         assert p.R >= sh and p.S >= sw, "fused BN reduction: the dgrad has to write every pixel"
         assert x.shape == dx.shape and x.dtype == dx.dtype and (y is None or (y.shape == dx.shape and y.dtype == dx.dtype))
         n_px = dx.shape[0] * dx.shape[1] * dx.shape[2]
@@ -138,6 +148,8 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
     rc = lib.dpa_conv_igemm(ctypes.byref(p), _DT[dy.dtype], 1, native.stream_ptr())
     if rc == 4 and addend2 is not None:
         raise CompactAddendUnsupported("this launch does not take the pre-split fp32 kernel")
+    if rc == 5:
+        raise SecondBnUnsupported("this launch does not take the pre-split fp32 kernel")
     if rc:
         raise RuntimeError(f"dpa_conv_igemm(dgrad) rejected geometry rc={rc}")
     return int(p.stats_rows_used) if bn_reduce is not None else 0

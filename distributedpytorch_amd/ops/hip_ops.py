@@ -8,7 +8,7 @@ import torch
 
 from . import native
 from .hip_conv import (conv_dgrad, conv_fprop, conv_wgrad, out_size, stats_rows,  # noqa: F401
-                       wgrad_workspace_numel, _check_nhwc, split3_planes, last_stats_rows, bn_reduce_rows, weight_prep, CompactAddendUnsupported)
+                       wgrad_workspace_numel, _check_nhwc, split3_planes, last_stats_rows, bn_reduce_rows, weight_prep, CompactAddendUnsupported, SecondBnUnsupported)
 from .native import F32, I32, I64, VP, ptr, stream_ptr
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}

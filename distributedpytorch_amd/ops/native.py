@@ -34,6 +34,7 @@ class ConvParams(ctypes.Structure):
     _fields_ = [
         ("src", VP), ("wgt", VP), ("dst", VP), ("bias", VP), ("stats", VP), ("addend", VP), ("stats_shift", VP), ("wgt3", VP), ("wgt3_plane", I64),
         ("bnr_x", VP), ("bnr_y", VP), ("bnr_mean", VP), ("bnr_invstd", VP), ("bnr_mscale", VP), ("bnr_mshift", VP), ("bnr_slab", VP), ("bnr_bits", VP),
+        ("bnr2_x", VP), ("bnr2_mean", VP), ("bnr2_invstd", VP), ("bnr2_slab", VP), ("bnr2_cs", I32), ("bnr2_pad", I32),
         ("bnr_cs", I32), ("bnr_y_cs", I32), ("bnr_row0", I32), ("bnr_pad", I32), ("oscale", VP),
         ("addend2", VP), ("a2_H", I32), ("a2_W", I32), ("a2_cs", I32), ("a2_pad", I32),
         ("sN", I32), ("sH", I32), ("sW", I32), ("sC", I32), ("s_cs", I32), ("s_co", I32),

@@ -52,6 +52,10 @@ def conv_fprop(x, w, y, stride, pad, bias=None, relu=False, stats=None, addend=N
     return y
 
 
+class SecondBnUnsupported(RuntimeError):
+    """conv_dgrad(bn_reduce=(..., bits, second)) on a launch that does not go to the pre-split fp32 kernel: nothing was launched."""
+
+
 class CompactAddendUnsupported(RuntimeError):
     """conv_dgrad(addend2=...) on a launch that does not go to the pre-split fp32 kernel: nothing was launched."""
 
@@ -69,6 +73,7 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
         g[:, ::2, ::2, :] += addend2.float()
     if bn_reduce is not None:       # fused BatchNorm-backward reduction (csrc/hip/conv_common.h: BnReduceLane)
         x, y, mean, invstd, mscale, mshift, slab = bn_reduce[:7]      # (an eighth element: y's mask as bits, same mask)
+        second = bn_reduce[8] if len(bn_reduce) > 8 else None         # (a ninth: (x2, mean2, invstd2, slab2), see hip_conv)
         if y is not None:
             g = g * (y > 0)
         elif mscale is not None:
@@ -77,6 +82,11 @@ def conv_dgrad(dy, wt, dx, stride, pad, addend=None, wt3=None, bn_reduce=None, a
         slab.zero_()
         slab[0, 0] = gs.sum(0)
         slab[0, 1] = (gs * ((x.float().reshape(-1, c) - mean) * invstd)).sum(0)
+        if second is not None:
+            x2, mean2, invstd2, slab2 = second
+            slab2.zero_()
+            slab2[0, 0] = gs.sum(0)
+            slab2[0, 1] = (gs * ((x2.float().reshape(-1, c) - mean2) * invstd2)).sum(0)
     dx.copy_(g.to(dx.dtype))
     return 1
 

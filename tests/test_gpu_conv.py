@@ -348,10 +348,30 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
         fused = torch.full((N, H, W, C), float("nan"), device="cuda", dtype=dtype)
         if use_addend:
             fused.copy_(addend)
-        used = hip_conv.conv_dgrad(dy, wt, fused, (s, s), (pd, pd), addend=fused if use_addend else None, wt3=wt3,
-                                   bn_reduce=(z, y if mask in ("y", "ybits") else None, mean, invstd,
-                                              msc if mask == "x" else None, msh if mask == "x" else None, slab)
-                                   + ((_pack_mask_bits(y),) if mask == "ybits" else ()))
+        # (with the bit mask: also a SECOND BatchNorm under the same ReLU - sum dz * xhat2 into a slab of its own - where the
+        # launch takes the pre-split fp32 kernel; any other launch must refuse it before anything runs)
+        second = None
+        if mask == "ybits":
+            z2 = (torch.randn(N, H, W, C, device="cuda", generator=g) * 1.5 - 0.3).to(dtype)
+            mean2 = torch.randn(C, device="cuda", generator=g) * 0.3 - 0.3
+            invstd2 = torch.rand(C, device="cuda", generator=g) + 0.4
+            second = (z2, mean2, invstd2, torch.full((rows, 2, C), float("nan"), device="cuda"))
+        reduce_args = (z, y if mask in ("y", "ybits") else None, mean, invstd,
+                       msc if mask == "x" else None, msh if mask == "x" else None, slab) \
+            + ((_pack_mask_bits(y),) if mask == "ybits" else ())
+        did_second = False
+        if second is not None:
+            try:
+                used = hip_conv.conv_dgrad(dy, wt, fused, (s, s), (pd, pd), addend=fused if use_addend else None, wt3=wt3,
+                                           bn_reduce=reduce_args + (second,))
+                did_second = True
+            except hip_conv.SecondBnUnsupported:
+                assert not (dtype == torch.float32 and fp32_mode == "x6" and wt3 is not None and C > 32), "the pre-split kernel refused"
+                torch.cuda.synchronize()
+                assert torch.isnan(slab).all()                     # nothing was launched
+        if not did_second:
+            used = hip_conv.conv_dgrad(dy, wt, fused, (s, s), (pd, pd), addend=fused if use_addend else None, wt3=wt3,
+                                       bn_reduce=reduce_args)
         assert 0 < used <= rows
         assert torch.equal(fused, want)                      # same arithmetic, masked
         got = slab[:used].double().sum(0)
@@ -363,6 +383,13 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
         scale_q = (wd * xh).abs().sum(0).clamp_min(1e-6)
         assert ((got[0] - ref_s).abs() / scale_s).max().item() < 2e-6
         assert ((got[1] - ref_q).abs() / scale_q).max().item() < 2e-6
+        if did_second:
+            got2 = second[3][:used].double().sum(0)
+            xh2 = (z2.double().reshape(-1, C) - mean2.double()) * invstd2.double()
+            ref_q2 = (wd * xh2).sum(0)
+            scale_q2 = (wd * xh2).abs().sum(0).clamp_min(1e-6)
+            assert torch.equal(second[3][:used, 0], slab[:used, 0])          # the same sum dz, row by row
+            assert ((got2[1] - ref_q2).abs() / scale_q2).max().item() < 2e-6
 
 
 @pytest.fixture
@@ -482,35 +509,47 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
         # the downsample blocks' compact gradients (nn/layers.py: Conv2d._dgrad) against full-resolution ones, and the ReLU
         # masks as bits (ConvBNAct) against the fused epilogues reading y itself: same bits in every gradient
         from distributedpytorch_amd.nn import layers
-        keep = layers._COMPACT_DOWN, layers._RELU_BITS
+        keep = layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2
         try:
             res = {}
-            for compact, relu_bits in ((True, True), (False, True), (True, False)):
-                layers._COMPACT_DOWN, layers._RELU_BITS = compact, relu_bits
+            for compact, relu_bits, bn2 in ((True, True, False), (False, True, False), (True, False, False), (True, True, True)):
+                layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = compact, relu_bits, bn2
                 torch.manual_seed(5)
                 net, _ = get_model("resnet50", 10, device="cuda", dtype=torch.float32)
-                made, with_bits = [], []
+                made, with_bits, with_bn2 = [], [], []
                 orig = layers.ops.conv_dgrad
 
                 def spy(*a, **kw):
                     made.append(kw.get("addend2") is not None)
                     with_bits.append(kw.get("bn_reduce") is not None and len(kw["bn_reduce"]) > 7)
+                    with_bn2.append(kw.get("bn_reduce") is not None and len(kw["bn_reduce"]) > 8)
                     return orig(*a, **kw)
                 layers.ops.conv_dgrad = spy
                 try:
                     _, loss, _ = framework_step(net, x, y)
                 finally:
                     layers.ops.conv_dgrad = orig
-                res[(compact, relu_bits)] = (loss, grads_by_name(net), sum(made), sum(with_bits))
-            base = res[(True, True)]
-            assert base[2] == 3 and res[(False, True)][2] == 0       # layer2.0, layer3.0, layer4.0 took a compact addend
-            assert base[3] == 15 and res[(True, False)][3] == 0      # conv1 of every block after a residual ReLU read the bits
-            for other in ((False, True), (True, False)):
+                res[(compact, relu_bits, bn2)] = (loss, grads_by_name(net), sum(made), sum(with_bits), sum(with_bn2))
+            base = res[(True, True, False)]
+            assert base[2] == 3 and res[(False, True, False)][2] == 0     # layer2.0, layer3.0, layer4.0 took a compact addend
+            assert base[3] == 15 and res[(True, False, False)][3] == 0    # conv1 of every block after a residual ReLU read the bits
+            for other in ((False, True, False), (True, False, False)):
                 assert res[other][0] == base[0]
                 for k, gk in base[1].items():
                     assert torch.equal(res[other][1][k], gk), (other, k)
+            # the downsample branches' BatchNorm reductions in the same epilogues (layer1.1 .. layer4.1 conv1): other
+            # summation order than bn_bwd_reduce's, so to rounding (see the docstring for what that means here)
+            fused2 = res[(True, True, True)]
+            assert fused2[4] == 4 and base[4] == 0
+            assert abs(fused2[0] - base[0]) < 1e-4 * max(1.0, abs(base[0]))
+            ga = torch.cat([fused2[1][k].double().flatten() for k in base[1]])
+            gb = torch.cat([g.double().flatten() for g in base[1].values()])
+            assert 1 - torch.dot(ga, gb).item() / (ga.norm().item() * gb.norm().item()) < 2e-3
+            for k in base[1]:
+                if "downsample.1" in k:       # the BatchNorm parameters whose gradients ARE those sums
+                    torch.testing.assert_close(fused2[1][k], base[1][k], rtol=2e-3, atol=1e-4 * gmax)
         finally:
-            layers._COMPACT_DOWN, layers._RELU_BITS = keep
+            layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = keep
     finally:
         lib.dpa_x6s_knob(1, 1)
         set_fp32_mode(prev)
