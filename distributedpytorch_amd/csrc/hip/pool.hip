@@ -95,11 +95,32 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
 // input pixels (x 16 bytes of channels).  The block is covered by exactly the four windows (A-1..A) x (B-1..B), so their
 // dy / argmax chunks are loaded ONCE for four outputs (the generic gather loads 2.25 windows per pixel, with divergent trip
 // counts 1 / 2 / 4 inside a wave and four integer divisions): 2.05 -> ~1 ms on the ResNet-50 stem at batch 1024.
-template <typename T>
+// RED: the pool follows BatchNorm + ReLU (a network stem) and dx is the gradient w.r.t. that BatchNorm's output: the kernel
+// also reads the BatchNorm's input z, masks with scale * z + shift > 0 and writes its block's partial sums of the
+// BatchNorm-backward reduction (sum dz, sum dz * xhat) to slab[blockIdx][2][C] - the pass bn_bwd_reduce_kernel would make
+// over dx and z right after (one read of a 3.3 GB tensor less on the ResNet-50 stem at batch 1024).  dx itself is written
+// unmasked, as without RED (bn_bwd_dx_kernel masks from z again).  Needs 256 % (C / VEC) == 0: a thread's channel chunk
+// is then the same in every iteration of its grid-stride loop.
+struct PoolBn {
+  const void* z; int z_cs, pad;
+  const float *scale, *shift, *mean, *invstd;
+  float* slab;
+};
+template <typename T, bool RED = false>
 __global__ void __launch_bounds__(256) maxpool_bwd_k3s2_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
-                                                               T* __restrict__ dx, PoolP p, int dy_cs, int dx_cs, int nA, int nB) {
+                                                               T* __restrict__ dx, PoolP p, int dy_cs, int dx_cs, int nA, int nB,
+                                                               PoolBn bn) {
   constexpr int VEC = 16 / sizeof(T);
   const uint32_t cpr = (uint32_t)(p.C / VEC);
+  float rs[VEC], rq[VEC], mu[VEC], is[VEC], msc[VEC], msh[VEC];
+  if constexpr (RED) {
+    const int c0 = (int)(threadIdx.x % cpr) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      rs[e] = 0.f; rq[e] = 0.f;
+      mu[e] = bn.mean[c0 + e]; is[e] = bn.invstd[c0 + e]; msc[e] = bn.scale[c0 + e]; msh[e] = bn.shift[c0 + e];
+    }
+  }
   const uint32_t total = (uint32_t)p.N * nA * nB * cpr;          // < 2^31 (checked on the host)
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -142,8 +163,33 @@ __global__ void __launch_bounds__(256) maxpool_bwd_k3s2_kernel(const T* __restri
           if (j == 0 && l == 0) acc += tp[0][0][e] == (unsigned char)8 ? g[0][0][e] : 0.f;
           o.set(e, acc);
         }
-        o.store(dx + ((long long)((int)n * p.H + hi) * p.W + wi) * dx_cs + c);
+        const long long ipix = (long long)((int)n * p.H + hi) * p.W + wi;
+        o.store(dx + ipix * dx_cs + c);
+        if constexpr (RED) {
+          Vec16<T> zv; zv.load(reinterpret_cast<const T*>(bn.z) + ipix * bn.z_cs + c);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float ze = zv.get(e);
+            const float d = (ze * msc[e] + msh[e] > 0.f) ? o.get(e) : 0.f;      // (of the value as stored)
+            rs[e] += d; rq[e] += d * (ze - mu[e]) * is[e];
+          }
+        }
       }
+  }
+  if constexpr (RED) {
+    __shared__ float red[2][256][VEC > 4 ? 9 : 5];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[0][tid][e] = rs[e]; red[1][tid][e] = rq[e]; }
+    __syncthreads();
+    if ((uint32_t)tid < cpr) {
+      for (uint32_t l = 1; l < 256u / cpr; ++l)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { rs[e] += red[0][l * cpr + tid][e]; rq[e] += red[1][l * cpr + tid][e]; }
+      float* o = bn.slab + (size_t)blockIdx.x * 2 * p.C + (size_t)tid * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { o[e] = rs[e]; o[p.C + e] = rq[e]; }
+    }
   }
 }
 
@@ -394,14 +440,36 @@ DPA_API int dpa_maxpool_bwd(const void* dy, const unsigned char* idx, void* dx, 
     const int nB = (p.W - 1 + p.pw) / 2 + 1 > p.Wo ? (p.W - 1 + p.pw) / 2 + 1 : p.Wo;
     const long long blocks = (long long)p.N * nA * nB * (p.C / vec);
     if (blocks < 0x7fffffffLL) {
-      if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<bf16_t>, dim3(dpa_grid(blocks, 256)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, p, dy_cs, dx_cs, nA, nB);
-      else            hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<float>, dim3(dpa_grid(blocks, 256)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, p, dy_cs, dx_cs, nA, nB);
+      if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<bf16_t>, dim3(dpa_grid(blocks, 256)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, p, dy_cs, dx_cs, nA, nB, PoolBn{});
+      else            hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<float>, dim3(dpa_grid(blocks, 256)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, p, dy_cs, dx_cs, nA, nB, PoolBn{});
       return dpa_launch_rc();
     }
   }
   if (dtype == 1) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, p, dy_cs, dx_cs);
   else            hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(dpa_grid(total, 256)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, p, dy_cs, dx_cs);
   return dpa_launch_rc();
+}
+// 3x3 / stride-2 max-pool backward + the partial sums of the BatchNorm(+ReLU) in front of the pool (see the kernel).  Returns
+// the number of slab rows written (>= 1), or 0 when this geometry is not taken (nothing launched: the caller runs the two
+// separate kernels), or a negative launch error.  slab: [>= 2048][2][C] floats.
+DPA_API int dpa_maxpool_bwd_bn(const void* dy, const unsigned char* idx, void* dx, const PoolP* pp, int dy_cs, int dx_cs,
+                                int dtype, hipStream_t s, const void* z, int z_cs, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, float* slab) {
+  PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;
+  static const int on = [] { const char* e = getenv("DPA_POOL_BN"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || !(p.kh == 3 && p.kw == 3 && p.sh == 2 && p.sw == 2 && p.ph <= 1 && p.pw <= 1)) return 0;
+  const int cpr = p.C / vec;
+  if (cpr < 1 || cpr > 256 || 256 % cpr || p.C % vec) return 0;
+  const int nA = (p.H - 1 + p.ph) / 2 + 1 > p.Ho ? (p.H - 1 + p.ph) / 2 + 1 : p.Ho;
+  const int nB = (p.W - 1 + p.pw) / 2 + 1 > p.Wo ? (p.W - 1 + p.pw) / 2 + 1 : p.Wo;
+  const long long blocks = (long long)p.N * nA * nB * cpr;
+  if (blocks >= 0x7fffffffLL) return 0;
+  const int grid = dpa_grid(blocks, 256);
+  PoolBn bn{z, z_cs, 0, scale, shift, mean, invstd, slab};
+  if (dtype == 1) hipLaunchKernelGGL((maxpool_bwd_k3s2_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, p, dy_cs, dx_cs, nA, nB, bn);
+  else            hipLaunchKernelGGL((maxpool_bwd_k3s2_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, p, dy_cs, dx_cs, nA, nB, bn);
+  const int rc = dpa_launch_rc();
+  return rc ? -rc : grid;
 }
 DPA_API int dpa_avgpool_fwd(const void* x, void* y, const PoolP* pp, int adaptive, int dtype, hipStream_t s) {
   PoolP p = *pp; const int vec = dtype == 1 ? 8 : 4;

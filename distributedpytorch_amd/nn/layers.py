@@ -385,8 +385,9 @@ class BatchNorm2d:
         return dx_out
 
 
-def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m, accumulate=False):
-    """BatchNorm2d.backward when a dgrad epilogue already masked dy and reduced it (Act.bn_slab)."""
+def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m, accumulate=False, mask_from_x=False):
+    """BatchNorm2d.backward when a dgrad epilogue already masked dy and reduced it (Act.bn_slab).  mask_from_x: the sums are
+    of the masked gradient but dy itself is not masked (ConvBNReLUPool): bn_bwd_dx masks from z."""
     st = bn.store
     a = bn.aux(ctx.device)
     dg = st.gview(bn.gamma) if bn.trainable else None
@@ -395,7 +396,8 @@ def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m, accumulate=False):
     if bn.trainable:
         ctx.tape.ready(bn.gamma)
         ctx.tape.ready(bn.beta)
-    ops.bn_bwd_dx(dy, z, a[6:9], dx_out, accumulate=accumulate)
+    ms, mh = (a[2], a[3]) if mask_from_x else (None, None)
+    ops.bn_bwd_dx(dy, z, a[6:9], dx_out, mask_scale=ms, mask_shift=mh, accumulate=accumulate)
     return dx_out
 
 
@@ -508,8 +510,18 @@ class ConvBNReLUPool:
                 dyp = y.grad
                 y.grad = None
                 dy = ctx.empty((n, ho, wo, cp))
-                ops.maxpool_bwd(dyp, idx, dy, pool.ksize, pool.stride, pool.padding)
-                dz = bn.backward(ctx, dy, None, z, z, mask_from_x=True)      # dx overwrites z (dead after this)
+                # the pool's backward also makes the BatchNorm's backward reduction where its kernel can (3x3 / stride 2):
+                # one read of the full-resolution gradient less
+                rows = 0
+                if _FUSE_BN_BWD and ctx.training:
+                    a = bn.aux(ctx.device)
+                    slab = ctx.empty((2048, 2, cp), dtype=torch.float32)
+                    rows = ops.maxpool_bwd_bn(dyp, idx, dy, pool.ksize, pool.stride, pool.padding, z, a[2], a[3], a[0], a[1], slab)
+                if rows:
+                    dz = _bn_backward_from_slab(bn, ctx, dy, z, z, slab[:rows], m, mask_from_x=True)
+                else:
+                    ops.maxpool_bwd(dyp, idx, dy, pool.ksize, pool.stride, pool.padding)
+                    dz = bn.backward(ctx, dy, None, z, z, mask_from_x=True)      # dx overwrites z (dead after this)
                 conv.backward_raw(ctx, x, dz)
             ctx.tape.push(bw)
         return y

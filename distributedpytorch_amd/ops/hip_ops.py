@@ -221,6 +221,20 @@ def maxpool_bwd(dy, idx, dx, ksize, stride, pad):
     return dx
 
 
+def maxpool_bwd_bn(dy, idx, dx, ksize, stride, pad, z, scale, shift, mean, invstd, slab):
+    """maxpool_bwd + the partial sums of the backward reduction of the BatchNorm(+ReLU) in front of the pool (input z, mask
+    scale * z + shift > 0) into slab [>= 2048, 2, C].  Returns the slab rows written, or 0 when the geometry is not taken
+    (nothing launched)."""
+    p = _poolp(dx, dy, ksize, stride, pad)
+    assert slab.dtype == torch.float32 and slab.is_contiguous() and slab.shape[0] >= 2048 and tuple(slab.shape[1:]) == (2, dx.shape[3])
+    assert z.shape == dx.shape and z.dtype == dx.dtype
+    rows = _lib().dpa_maxpool_bwd_bn(ptr(dy), ptr(idx), ptr(dx), ctypes.byref(p), p.y_cs, p.x_cs, _DT[dy.dtype], stream_ptr(),
+                                     ptr(z), _mc(z)[2], ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(slab))
+    if rows < 0:
+        raise RuntimeError(f"dpa_maxpool_bwd_bn: launch error {-rows}")
+    return int(rows)
+
+
 def avgpool_fwd(x, y, ksize, stride, pad, adaptive=False):
     p = _poolp(x, y, ksize or (1, 1), stride or (1, 1), pad or (0, 0))
     _lib().dpa_avgpool_fwd(ptr(x), ptr(y), ctypes.byref(p), int(adaptive), _DT[x.dtype], stream_ptr())

@@ -66,7 +66,7 @@ def lib_path(name: str) -> str:
 # entry points whose int return value is NOT a launch status (sizes, counts, modes) or is checked by its own caller
 _NOT_LAUNCH = {"dpa_conv_params_size", "dpa_wgrad_params_size", "dpa_pool_params_size", "dpa_aug_params_size",
                "dpa_bn_slab_rows", "dpa_conv_stats_rows", "dpa_conv_wgrad_workspace", "dpa_get_fp32_mode",
-               "dpa_set_fp32_mode", "dpa_x6p_min_tiles", "dpa_x6p_knob", "dpa_wgrad_knob", "dpa_x6s_knob", "dpa_x6p_plausible", "dpa_weight_prep_seg_size", "dpa_conv_igemm", "dpa_conv_wgrad", "dpa_init_workspaces"}
+               "dpa_set_fp32_mode", "dpa_x6p_min_tiles", "dpa_x6p_knob", "dpa_wgrad_knob", "dpa_x6s_knob", "dpa_maxpool_bwd_bn", "dpa_x6p_plausible", "dpa_weight_prep_seg_size", "dpa_conv_igemm", "dpa_conv_wgrad", "dpa_init_workspaces"}
 
 
 class KernelLaunchError(RuntimeError):

@@ -333,6 +333,16 @@ def maxpool_bwd(dy, idx, dx, ksize, stride, pad):
     return dx
 
 
+def maxpool_bwd_bn(dy, idx, dx, ksize, stride, pad, z, scale, shift, mean, invstd, slab):
+    maxpool_bwd(dy, idx, dx, ksize, stride, pad)
+    c = dx.shape[3]
+    d = (dx.float() * ((z.float() * scale + shift) > 0)).reshape(-1, c)
+    slab.zero_()
+    slab[0, 0] = d.sum(0)
+    slab[0, 1] = (d * ((z.float().reshape(-1, c) - mean) * invstd)).sum(0)
+    return 1
+
+
 def avgpool_fwd(x, y, ksize, stride, pad, adaptive=False):
     if adaptive:
         out = F.adaptive_avg_pool2d(_nchw(x).float(), (y.shape[1], y.shape[2]))

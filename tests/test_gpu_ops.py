@@ -392,3 +392,44 @@ def test_bn_apply_writes_the_relu_mask_as_bits(m, c, dtype):
         words = (pos << torch.arange(32, dtype=torch.int64, device="cuda")).sum(-1)
         want = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
         assert torch.equal(bits, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,pad", [((3, 23, 18, 64), 1), ((2, 16, 16, 64), 0), ((2, 9, 11, 128), 1), ((1, 12, 12, 24), 1)],
+                         ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_maxpool_bwd_with_the_stem_batchnorm_reduction(shape, pad, dtype):
+    """maxpool_bwd_bn: the same dx as maxpool_bwd, bit for bit, and slab rows that sum to what bn_bwd_reduce (masked from z)
+    makes of that dx - checked against a float64 sum.  C = 24 (6 or 3 chunks of 16 bytes per row, no divisor of 256) is not taken."""
+    from distributedpytorch_amd.ops import hip_ops as H, ref_ops as R
+    n, h, w, c = shape
+    k, s = 3, 2
+    ho, wo = R.pool_out_size(h, k, s, pad, False), R.pool_out_size(w, k, s, pad, False)
+    g = torch.Generator(device="cuda").manual_seed(h * w + c)
+    z = torch.randn(shape, device="cuda", generator=g).to(dtype)
+    scale = torch.rand(c, device="cuda", generator=g) + 0.5
+    shift = torch.randn(c, device="cuda", generator=g) * 0.3
+    mean = torch.randn(c, device="cuda", generator=g) * 0.1
+    invstd = torch.rand(c, device="cuda", generator=g) + 0.5
+    yp = torch.empty(n, ho, wo, c, device="cuda", dtype=dtype)
+    idx = torch.empty(n, ho, wo, c, device="cuda", dtype=torch.uint8)
+    H.maxpool_fwd(z, yp, idx, (k, k), (s, s), (pad, pad), scale=scale, shift=shift)
+    dyp = torch.randn(n, ho, wo, c, device="cuda", generator=g).to(dtype)
+    dx0 = torch.empty_like(z)
+    H.maxpool_bwd(dyp, idx, dx0, (k, k), (s, s), (pad, pad))
+    dx1 = torch.full_like(z, float("nan"))
+    slab = torch.full((2048, 2, c), float("nan"), device="cuda")
+    rows = H.maxpool_bwd_bn(dyp, idx, dx1, (k, k), (s, s), (pad, pad), z, scale, shift, mean, invstd, slab)
+    if 256 % (c // (4 if dtype == torch.float32 else 8)):      # C = 24: 6 (fp32) or 3 (bf16) chunks per row
+        assert rows == 0
+        return
+    assert 1 <= rows <= 2048
+    assert torch.equal(dx0, dx1)
+    d = dx0.double() * ((z.float() * scale + shift) > 0)
+    want_s = d.sum((0, 1, 2))
+    want_q = (d * ((z.double() - mean.double()) * invstd.double())).sum((0, 1, 2))
+    got = slab[:rows].double().sum(0)
+    assert torch.isnan(slab[rows:]).all()
+    mag = d.abs().sum((0, 1, 2)).max().item()
+    assert (got[0] - want_s).abs().max().item() <= 1e-5 * mag
+    assert (got[1] - want_q).abs().max().item() <= 3e-5 * mag
