@@ -180,7 +180,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, int x_cs, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res, int r_cs,
                                                        T* __restrict__ y, int y_cs, long long M, int C, int relu,
-                                                       int rowsPerBlock, uint32_t* __restrict__ bits) {
+                                                       int rowsPerBlock, uint32_t* __restrict__ bits,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift) {
+  // rscale / rshift (or null): the residual is the INPUT of a second BatchNorm (the downsample branch of a ResNet block,
+  // ConvBNAct(defer_apply=True)): res * rscale + rshift is added - that BatchNorm's output never goes through memory.
   // bits (or null): [M][C / 32] words, bit b of word w = (y[row][32 w + b] > 0) - the ReLU mask a later fused dgrad
   // epilogue reads instead of y itself (1 / 32 of the bytes).  A thread owns VEC channels; the 32 / VEC adjacent lanes of a
   // word OR their bits together with shuffles (C % 32 == 0: a word's lanes are always active together).
@@ -209,6 +212,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
       sc[e] = a.x; sc[e + 1] = a.y; sc[e + 2] = a.z; sc[e + 3] = a.w;
       sh[e] = b.x; sh[e + 1] = b.y; sh[e + 2] = b.z; sh[e + 3] = b.w;
     }
+    float rsc[VEC], rsh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { rsc[e] = rscale ? rscale[c + e] : 1.f; rsh[e] = rscale ? rshift[c + e] : 0.f; }
     // UNR rows per trip, every load issued before the first use: a streaming kernel needs the bytes in flight
     // (one row per trip ran at 5.1 TB/s where torch's 4-wide add reaches 6.0: scripts/micro/hbm_bw.py)
     constexpr int UNR = 4;
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float f = v[u].get(e) * sc[e] + sh[e];
-          if (res) f += rv[u].get(e);
+          if (res) f += rscale ? rv[u].get(e) * rsc[e] + rsh[e] : rv[u].get(e);
           if (relu) f = fmaxf(f, 0.f);
           o.set(e, f);
           pos |= (o.get(e) > 0.f ? 1u : 0u) << e;      // (of the value as stored)
@@ -245,7 +251,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float f = v.get(e) * sc[e] + sh[e];
-        if (res) f += rv.get(e);
+        if (res) f += rscale ? rv.get(e) * rsc[e] + rsh[e] : rv.get(e);
         if (relu) f = fmaxf(f, 0.f);
         o.set(e, f);
         pos |= (o.get(e) > 0.f ? 1u : 0u) << e;
@@ -481,13 +487,14 @@ DPA_API int dpa_bn_eval_coeffs(int C, const float* gamma, const float* beta, con
   return dpa_launch_rc();
 }
 DPA_API int dpa_bn_apply(const void* x, int x_cs, const float* scale, const float* shift, const void* res, int r_cs, void* y,
-                          int y_cs, long long M, int C, int relu, int dtype, hipStream_t s, void* bits) {
-  if (bits && (C % 32)) return 1;
+                          int y_cs, long long M, int C, int relu, int dtype, hipStream_t s, void* bits, const float* rscale,
+                          const float* rshift) {
+  if ((bits && (C % 32)) || (rscale && !res) || (!rscale != !rshift)) return 1;
   int nb; const int rpb = ew_rows_per_block(M, C, dtype == 1 ? 2 : 4, &nb);
   if (dtype == 1) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, x_cs, scale, shift,
-                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb, (uint32_t*)bits);
+                                     (const bf16_t*)res, r_cs, (bf16_t*)y, y_cs, M, C, relu, rpb, (uint32_t*)bits, rscale, rshift);
   else            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, x_cs, scale, shift,
-                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu, rpb, (uint32_t*)bits);
+                                     (const float*)res, r_cs, (float*)y, y_cs, M, C, relu, rpb, (uint32_t*)bits, rscale, rshift);
   return dpa_launch_rc();
 }
 // slab: >= dpa_bn_slab_rows(M)*2*C floats; scratch >= ROWS_L2*2*C; sums: 2*C floats; coef: 3*C floats (for bn_bwd_dx)

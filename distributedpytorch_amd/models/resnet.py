@@ -45,11 +45,11 @@ class BasicBlock:
         if self.down is not None and _DOWN_LAST and sole_consumer and getattr(x, "bn_src", None) is not None:
             out = self.c1(ctx, x, relu=True, last_use=True)       # see _DOWN_LAST
             x.compact_ok = True     # conv1's dgrad is the next (and last) contribution to x.grad after the downsample's
-            identity = self.down(ctx, x, relu=False)
+            identity = self.down(ctx, x, relu=False, defer_apply=True)
             return self.c2(ctx, out, relu=True, residual=identity, last_use=True)
         # the downsample branch runs FIRST so that, in the reversed backward order, its dgrad comes after conv1's and
         # accumulates in place into x.grad: the stride-2 1x1 dgrad then touches only 1/4 of the pixels
-        identity = x if self.down is None else self.down(ctx, x, relu=False)
+        identity = x if self.down is None else self.down(ctx, x, relu=False, defer_apply=True)
         out = self.c1(ctx, x, relu=True, last_use=sole_consumer and self.down is None)
         return self.c2(ctx, out, relu=True, residual=identity, last_use=True)
 
@@ -70,9 +70,9 @@ class Bottleneck:
             out = self.c1(ctx, x, relu=True, last_use=True)       # see _DOWN_LAST
             out = self.c2(ctx, out, relu=True, last_use=True)
             x.compact_ok = True     # conv1's dgrad is the next (and last) contribution to x.grad after the downsample's
-            identity = self.down(ctx, x, relu=False)
+            identity = self.down(ctx, x, relu=False, defer_apply=True)
             return self.c3(ctx, out, relu=True, residual=identity, last_use=True)
-        identity = x if self.down is None else self.down(ctx, x, relu=False)      # first: see BasicBlock
+        identity = x if self.down is None else self.down(ctx, x, relu=False, defer_apply=True)      # first: see BasicBlock
         out = self.c1(ctx, x, relu=True, last_use=sole_consumer and self.down is None)
         out = self.c2(ctx, out, relu=True, last_use=True)
         return self.c3(ctx, out, relu=True, residual=identity, last_use=True)

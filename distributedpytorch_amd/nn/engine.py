@@ -39,7 +39,7 @@ def input_pad(c: int, dtype) -> int:
 
 class Act:
     """An NHWC activation (possibly a channel slice of a wider buffer) plus its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact", "bn_lin", "bn_src2", "bn_slab2")
+    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact", "bn_lin", "bn_src2", "bn_slab2", "bn_defer")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = False):
         self.data = data
@@ -63,6 +63,9 @@ class Act:
         self.bn_lin = None
         self.bn_src2 = None
         self.bn_slab2 = None
+        # bn_defer = (scale, shift): data is the INPUT of a BatchNorm whose apply pass was left to the consumer (a ConvBNAct
+        # taking this activation as its residual applies both BatchNorms in one kernel)
+        self.bn_defer = None
 
     @property
     def shape(self):

@@ -25,6 +25,9 @@ _FOLD_EVAL_BN = os.environ.get("DPA_FOLD_EVAL_BN", "1") != "0"
 
 # DPA_FUSE_BN_BWD=0: never fuse the BatchNorm-backward reduction into the dgrad epilogue (A/B switch)
 _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
+# DPA_DEFER_DOWN_BN=0: the downsample branch of a ResNet block applies its BatchNorm itself (a pass over the activations of
+# its own) instead of leaving it to the bn_apply of the block's last BatchNorm + add + ReLU
+_DEFER_DOWN_BN = os.environ.get("DPA_DEFER_DOWN_BN", "1") != "0"
 # DPA_COMPACT_DOWN=0: the data gradient of a 1x1 / stride-2 downsample convolution is always a full-resolution tensor
 # (A/B switch; see Conv2d._dgrad)
 _COMPACT_DOWN = os.environ.get("DPA_COMPACT_DOWN", "1") != "0"
@@ -412,16 +415,24 @@ class ConvBNAct:
     def __init__(self, conv: Conv2d, bn: BatchNorm2d):
         self.conv, self.bn = conv, bn
 
-    def __call__(self, ctx: Context, x: Act, relu=True, residual: Act = None, out=None, last_use=False) -> Act:
+    def __call__(self, ctx: Context, x: Act, relu=True, residual: Act = None, out=None, last_use=False,
+                 defer_apply=False) -> Act:
         """last_use: no consumer of x comes after this layer in the backward pass, i.e. every other consumer of x (a
-        residual connection, a parallel branch) is called LATER in the forward pass - see Conv2d.backward_raw."""
+        residual connection, a parallel branch) is called LATER in the forward pass - see Conv2d.backward_raw.
+        defer_apply (no ReLU, no residual): the caller hands the result to ONE ConvBNAct as its residual and nowhere else;
+        the result may then be the convolution's output with Act.bn_defer = (scale, shift), and that consumer's bn_apply
+        applies this BatchNorm on the fly - its output is never written or read."""
         conv, bn = self.conv, self.bn
+        defer_apply = defer_apply and _DEFER_DOWN_BN and not relu and residual is None and out is None
+        res_defer = residual.bn_defer if residual is not None else None
         n, h, w, _ = x.data.shape
         ho, wo = conv.out_hw(h, w)
         m, cp = n * ho * wo, pad_to(conv.cout)
         if _FOLD_EVAL_BN and not ctx.training and not ctx.grad_enabled and conv.b is None:
             # inference: the BatchNorm is a per-channel affine map of the conv output - applied in the conv epilogue together
             # with the residual connection and the ReLU, so evaluation runs no BatchNorm kernel over the activations at all
+            if res_defer is not None:
+                raise RuntimeError("a deferred BatchNorm output reached the folded evaluation path")
             a = bn.coeffs(ctx, None, m)
             if out is None:
                 out = ctx.empty((n, ho, wo, cp))
@@ -433,7 +444,9 @@ class ConvBNAct:
         if slab is not None:
             slab = slab[: conv.last_stats_rows]       # the rows the chosen kernel / tile plan actually wrote
         a = bn.coeffs(ctx, slab, m)
-        if out is None:
+        if defer_apply:
+            out = z
+        elif out is None:
             out = ctx.empty((n, ho, wo, cp))
         needs = x.needs_grad or conv.trainable or bn.trainable or (residual is not None and residual.needs_grad)
         # BatchNorm + residual + ReLU in training: the ReLU mask also as bits (1 / 32 of y's bytes) for the dgrad that
@@ -442,8 +455,13 @@ class ConvBNAct:
         if (_RELU_BITS and relu and residual is not None and ctx.training and ctx.grad_enabled and needs and _FUSE_BN_BWD
                 and ctx.cuda and out.dtype == torch.float32 and cp % 32 == 0 and out.is_contiguous()):
             bits = ctx.empty((m, cp // 32), dtype=torch.int32)
-        ops.bn_apply(z, a[2], a[3], out, residual=None if residual is None else residual.data, relu=relu, mask_bits=bits)
+        if not defer_apply:
+            rs, rh = res_defer if res_defer is not None else (None, None)
+            ops.bn_apply(z, a[2], a[3], out, residual=None if residual is None else residual.data, relu=relu, mask_bits=bits,
+                         res_scale=rs, res_shift=rh)
         y = Act(out, needs)
+        if defer_apply:
+            y.bn_defer = (a[2], a[3])
         if ctx.grad_enabled and needs:
             mask_from_x = relu and residual is None and ctx.training
             if relu and ctx.training:

@@ -84,8 +84,9 @@ def bn_eval_coeffs(gamma, beta, rm, rv, eps, scale, shift):
                               stream_ptr())
 
 
-def bn_apply(x, scale, shift, y, residual=None, relu=False, mask_bits=None):
-    """mask_bits: int32 [rows, C / 32] or None - written with bit b of word w = (y[row, 32 w + b] > 0) (C % 32 == 0): the
+def bn_apply(x, scale, shift, y, residual=None, relu=False, mask_bits=None, res_scale=None, res_shift=None):
+    """res_scale / res_shift: the residual is the input of a second BatchNorm, residual * res_scale + res_shift is added.
+    mask_bits: int32 [rows, C / 32] or None - written with bit b of word w = (y[row, 32 w + b] > 0) (C % 32 == 0): the
     ReLU mask for a fused dgrad epilogue (conv_dgrad(bn_reduce=(..., bits))) at 1 / 32 of y's bytes."""
     m, c, xcs = _mc(x)
     _, _, ycs = _mc(y)
@@ -93,7 +94,7 @@ def bn_apply(x, scale, shift, y, residual=None, relu=False, mask_bits=None):
     if mask_bits is not None:
         assert c % 32 == 0 and mask_bits.dtype == torch.int32 and mask_bits.is_contiguous() and mask_bits.numel() == m * (c // 32)
     _lib().dpa_bn_apply(ptr(x), xcs, ptr(scale), ptr(shift), ptr(residual), rcs, ptr(y), ycs, I64(m), c, int(relu),
-                        _DT[x.dtype], stream_ptr(), ptr(mask_bits))
+                        _DT[x.dtype], stream_ptr(), ptr(mask_bits), ptr(res_scale), ptr(res_shift))
     return y
 
 

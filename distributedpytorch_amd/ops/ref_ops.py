@@ -160,10 +160,10 @@ def bn_eval_coeffs(gamma, beta, rm, rv, eps, scale, shift):
     shift.copy_(b - rm * g * inv)
 
 
-def bn_apply(x, scale, shift, y, residual=None, relu=False, mask_bits=None):
+def bn_apply(x, scale, shift, y, residual=None, relu=False, mask_bits=None, res_scale=None, res_shift=None):
     out = x.float() * scale + shift
     if residual is not None:
-        out = out + residual.float()
+        out = out + (residual.float() if res_scale is None else residual.float() * res_scale + res_shift)
     if relu:
         out = out.clamp_min(0)
     y.copy_(out.to(y.dtype))

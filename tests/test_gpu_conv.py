@@ -509,11 +509,15 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
         # the downsample blocks' compact gradients (nn/layers.py: Conv2d._dgrad) against full-resolution ones, and the ReLU
         # masks as bits (ConvBNAct) against the fused epilogues reading y itself: same bits in every gradient
         from distributedpytorch_amd.nn import layers
-        keep = layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2
+        keep = layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2, layers._DEFER_DOWN_BN
         try:
             res = {}
-            for compact, relu_bits, bn2 in ((True, True, False), (False, True, False), (True, False, False), (True, True, True)):
-                layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = compact, relu_bits, bn2
+            for compact, relu_bits, bn2 in ((True, True, False), (False, True, False), (True, False, False), (True, True, True),
+                                            (True, True, "own_apply")):
+                # "own_apply": the downsample branches apply their BatchNorm themselves instead of leaving it to the block's
+                # last bn_apply (ConvBNAct(defer_apply=True)): the same fp32 operations, so the same bits
+                layers._DEFER_DOWN_BN = bn2 != "own_apply"
+                layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = compact, relu_bits, bn2 is True
                 torch.manual_seed(5)
                 net, _ = get_model("resnet50", 10, device="cuda", dtype=torch.float32)
                 made, with_bits, with_bn2 = [], [], []
@@ -533,7 +537,7 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
             base = res[(True, True, False)]
             assert base[2] == 3 and res[(False, True, False)][2] == 0     # layer2.0, layer3.0, layer4.0 took a compact addend
             assert base[3] == 15 and res[(True, False, False)][3] == 0    # conv1 of every block after a residual ReLU read the bits
-            for other in ((False, True, False), (True, False, False)):
+            for other in ((False, True, False), (True, False, False), (True, True, "own_apply")):
                 assert res[other][0] == base[0]
                 for k, gk in base[1].items():
                     assert torch.equal(res[other][1][k], gk), (other, k)
@@ -549,7 +553,7 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
                 if "downsample.1" in k:       # the BatchNorm parameters whose gradients ARE those sums
                     torch.testing.assert_close(fused2[1][k], base[1][k], rtol=2e-3, atol=1e-4 * gmax)
         finally:
-            layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = keep
+            layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2, layers._DEFER_DOWN_BN = keep
     finally:
         lib.dpa_x6s_knob(1, 1)
         set_fp32_mode(prev)

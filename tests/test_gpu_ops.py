@@ -392,6 +392,20 @@ def test_bn_apply_writes_the_relu_mask_as_bits(m, c, dtype):
         words = (pos << torch.arange(32, dtype=torch.int64, device="cuda")).sum(-1)
         want = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
         assert torch.equal(bits, want)
+    # the residual as the input of a second BatchNorm (res_scale / res_shift): what two passes make, bit for bit in fp32
+    # (in bf16 the intermediate is not rounded to bf16: compared to that rounding)
+    rs = torch.rand(c, device="cuda", generator=g) + 0.5
+    rh = torch.randn(c, device="cuda", generator=g) * 0.3
+    mid = torch.empty_like(x)
+    hip_ops.bn_apply(res, rs, rh, mid)
+    want = torch.empty_like(x)
+    hip_ops.bn_apply(x, scale, shift, want, residual=mid, relu=True)
+    got = torch.empty_like(x)
+    hip_ops.bn_apply(x, scale, shift, got, residual=res, relu=True, res_scale=rs, res_shift=rh)
+    if dtype == torch.float32:
+        assert torch.equal(got, want)
+    else:
+        torch.testing.assert_close(got.float(), want.float(), rtol=1e-2, atol=3e-2)
 
 
 @pytest.mark.gpu
