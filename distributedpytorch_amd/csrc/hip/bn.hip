@@ -11,6 +11,7 @@
 //   bn_bwd_dx      -> dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M)
 // All slabs are reduced in a fixed order: results are bitwise reproducible (no float atomics).
 #include "common.h"
+#include <type_traits>
 
 #define ROWS_L2 256  // rows of the second-level slab (= blocks along the row axis of slab_reduce: 32 left most CUs idle)
 
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
         for (int e = 0; e < VEC; ++e) {
           const float xe = xv[u].get(e);
           const float ge = (xe * msc[e] + msh[e] > 0.f) ? g[u].get(e) : 0.f;   // (no mask: 0*x + 1 > 0 always)
-          o.set(e, A[e] * ge + B[e] * xe + D[e] + (ACC ? av[u].get(e) : 0.f));
+          { const float r = fmaf(A[e], ge, fmaf(B[e], xe, D[e])); o.set(e, ACC ? r + av[u].get(e) : r); }   // (order fixed: = bn_bwd_dx2_kernel)
         }
         o.store(dx + (m + (long long)u * rowLanes) * dx_cs + c);
       }
@@ -410,10 +411,63 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ dz
       for (int e = 0; e < VEC; ++e) {
         const float xe = xv.get(e);
         const float ge = (xe * msc[e] + msh[e] > 0.f) ? g.get(e) : 0.f;
-        o.set(e, A[e] * ge + B[e] * xe + D[e] + (ACC ? av.get(e) : 0.f));
+        { const float r = fmaf(A[e], ge, fmaf(B[e], xe, D[e])); o.set(e, ACC ? r + av.get(e) : r); }
       }
       o.store(dx + m * dx_cs + c);
     }
+  }
+}
+
+// Two BatchNorms under one gradient (a ResNet block's last BatchNorm and the one of its downsample branch: both take
+// d(block output) as it is): dx1 = A1 dz + B1 x1 + D1 and dx2 = A2 dz + B2 x2 + D2 in one pass - dz is read once.  Same
+// per-element operations as two bn_bwd_dx_kernel launches without a mask.
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_dx2_kernel(const T* __restrict__ dz, int dz_cs, const T* x1, int x1_cs,
+                                                         const float* __restrict__ coef1, T* dx1, int dx1_cs,
+                                                         const T* x2, int x2_cs, const float* __restrict__ coef2, T* dx2,
+                                                         int dx2_cs, long long M, int C, int rowsPerBlock) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int cpr = C / VEC;
+  const int colsPerPass = cpr < 256 ? cpr : 256;
+  const int rowLanes = 256 / colsPerPass;
+  const int col = threadIdx.x % colsPerPass, rl = threadIdx.x / colsPerPass;
+  if (rl >= rowLanes) return;
+  const long long r0 = (long long)blockIdx.x * rowsPerBlock;
+  long long r1 = r0 + rowsPerBlock; if (r1 > M) r1 = M;
+  for (int cb = col; cb < cpr; cb += colsPerPass) {
+    const int c = cb * VEC;
+    float A1[VEC], B1[VEC], D1[VEC], A2[VEC], B2[VEC], D2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      A1[e] = coef1[c + e]; B1[e] = coef1[C + c + e]; D1[e] = coef1[2 * C + c + e];
+      A2[e] = coef2[c + e]; B2[e] = coef2[C + c + e]; D2[e] = coef2[2 * C + c + e];
+    }
+    auto rows = [&](auto unr_tag, long long m) __attribute__((always_inline)) {
+      constexpr int U = decltype(unr_tag)::value;
+      Vec16<T> g[U], xa[U], xb[U];               // dx may alias x: each thread reads its chunks before writing them
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        g[u].load(dz + (m + (long long)u * rowLanes) * dz_cs + c);
+        xa[u].load(x1 + (m + (long long)u * rowLanes) * x1_cs + c);
+        xb[u].load(x2 + (m + (long long)u * rowLanes) * x2_cs + c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Vec16<T> oa, ob;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float ge = g[u].get(e);
+          oa.set(e, fmaf(A1[e], ge, fmaf(B1[e], xa[u].get(e), D1[e])));
+          ob.set(e, fmaf(A2[e], ge, fmaf(B2[e], xb[u].get(e), D2[e])));
+        }
+        oa.store(dx1 + (m + (long long)u * rowLanes) * dx1_cs + c);
+        ob.store(dx2 + (m + (long long)u * rowLanes) * dx2_cs + c);
+      }
+    };
+    constexpr int UNR = 4;                      // rows per trip, loads first (see bn_apply_kernel)
+    long long m = r0 + rl;
+    for (; m + (long long)(UNR - 1) * rowLanes < r1; m += (long long)UNR * rowLanes) rows(std::integral_constant<int, UNR>{}, m);
+    for (; m < r1; m += rowLanes) rows(std::integral_constant<int, 1>{}, m);
   }
 }
 
@@ -531,6 +585,16 @@ DPA_API int dpa_bn_bwd_dx(const void* dz, int dz_cs, const void* x, int x_cs, co
   if (dtype == 1) { if (accumulate) DPA_BWD_DX(bf16_t, true); else DPA_BWD_DX(bf16_t, false); }
   else            { if (accumulate) DPA_BWD_DX(float, true);  else DPA_BWD_DX(float, false); }
 #undef DPA_BWD_DX
+  return dpa_launch_rc();
+}
+DPA_API int dpa_bn_bwd_dx2(const void* dz, int dz_cs, const void* x1, int x1_cs, const float* coef1, void* dx1, int dx1_cs,
+                            const void* x2, int x2_cs, const float* coef2, void* dx2, int dx2_cs, long long M, int C, int dtype,
+                            hipStream_t s) {
+  int nb; const int rpb = ew_rows_per_block(M, C, dtype == 1 ? 2 : 4, &nb);
+  if (dtype == 1) hipLaunchKernelGGL(bn_bwd_dx2_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, dz_cs, (const bf16_t*)x1, x1_cs,
+                                     coef1, (bf16_t*)dx1, dx1_cs, (const bf16_t*)x2, x2_cs, coef2, (bf16_t*)dx2, dx2_cs, M, C, rpb);
+  else            hipLaunchKernelGGL(bn_bwd_dx2_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, dz_cs, (const float*)x1, x1_cs,
+                                     coef1, (float*)dx1, dx1_cs, (const float*)x2, x2_cs, coef2, (float*)dx2, dx2_cs, M, C, rpb);
   return dpa_launch_rc();
 }
 

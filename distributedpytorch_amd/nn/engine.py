@@ -39,7 +39,7 @@ def input_pad(c: int, dtype) -> int:
 
 class Act:
     """An NHWC activation (possibly a channel slice of a wider buffer) plus its gradient slot."""
-    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact", "bn_lin", "bn_src2", "bn_slab2", "bn_defer")
+    __slots__ = ("data", "grad", "needs_grad", "grad_buf", "bn_src", "bn_slab", "compact_ok", "grad_compact", "bn_lin", "bn_src2", "bn_slab2", "bn_defer", "bn_dx_done")
 
     def __init__(self, data: torch.Tensor, needs_grad: bool = False):
         self.data = data
@@ -66,6 +66,9 @@ class Act:
         # bn_defer = (scale, shift): data is the INPUT of a BatchNorm whose apply pass was left to the consumer (a ConvBNAct
         # taking this activation as its residual applies both BatchNorms in one kernel)
         self.bn_defer = None
+        # bn_dx_done: the consumer's backward already ran this (bn_lin) BatchNorm's backward - parameter gradients and dx,
+        # left in place of z - together with its own (one pass over the shared gradient, ops.bn_bwd_dx2)
+        self.bn_dx_done = False
 
     @property
     def shape(self):

@@ -28,6 +28,8 @@ _FUSE_BN_BWD = os.environ.get("DPA_FUSE_BN_BWD", "1") != "0"
 # DPA_DEFER_DOWN_BN=0: the downsample branch of a ResNet block applies its BatchNorm itself (a pass over the activations of
 # its own) instead of leaving it to the bn_apply of the block's last BatchNorm + add + ReLU
 _DEFER_DOWN_BN = os.environ.get("DPA_DEFER_DOWN_BN", "1") != "0"
+# DPA_BN_DX2=0: bn3 and the downsample BatchNorm of a ResNet block compute their dx in separate passes over the gradient
+_BN_DX2 = os.environ.get("DPA_BN_DX2", "1") != "0"
 # DPA_COMPACT_DOWN=0: the data gradient of a 1x1 / stride-2 downsample convolution is always a full-resolution tensor
 # (A/B switch; see Conv2d._dgrad)
 _COMPACT_DOWN = os.environ.get("DPA_COMPACT_DOWN", "1") != "0"
@@ -388,6 +390,19 @@ class BatchNorm2d:
         return dx_out
 
 
+def _bn_finish_slab(bn, ctx, slab, m):
+    """Parameter gradients and the dx coefficients (aux rows 6-8) of a BatchNorm from its partial sums."""
+    st = bn.store
+    a = bn.aux(ctx.device)
+    dg = st.gview(bn.gamma) if bn.trainable else None
+    db = st.gview(bn.beta) if bn.trainable else None
+    ops.bn_bwd_from_slab(slab, m, a[0], a[1], st.view(bn.gamma), dg, db, a[4:6], a[6:9])
+    if bn.trainable:
+        ctx.tape.ready(bn.gamma)
+        ctx.tape.ready(bn.beta)
+    return a[6:9]
+
+
 def _bn_backward_from_slab(bn, ctx, dy, z, dx_out, slab, m, accumulate=False, mask_from_x=False):
     """BatchNorm2d.backward when a dgrad epilogue already masked dy and reduced it (Act.bn_slab).  mask_from_x: the sums are
     of the masked gradient but dy itself is not masked (ConvBNReLUPool): bn_bwd_dx masks from z."""
@@ -478,7 +493,20 @@ class ConvBNAct:
                 y.grad = None
                 slab, y.bn_slab, y.bn_src = y.bn_slab, None, None
                 slab2, y.bn_slab2, y.bn_src2, y.bn_lin = y.bn_slab2, None, None, None
-                if slab is not None:       # dy arrived masked, its partial sums are in the slab
+                if y.bn_dx_done:           # the consumer ran this BatchNorm's backward together with its own: z holds dx
+                    y.bn_dx_done = False
+                    conv.backward_raw(ctx, x, z, last_use=last_use)
+                    return
+                lin = residual.bn_lin if residual is not None else None
+                if (slab is not None and slab2 is not None and _BN_DX2 and lin is not None and residual.grad is None
+                        and residual.grad_buf is None and residual.needs_grad and lin[1].shape == z.shape):
+                    # both BatchNorms under this ReLU take dy as it is and both reductions are done: one pass for both dx
+                    c1 = _bn_finish_slab(bn, ctx, slab, m)
+                    c2 = _bn_finish_slab(lin[0], ctx, slab2, m)
+                    ops.bn_bwd_dx2(dy, z, c1, z, lin[1], c2, lin[1])
+                    dz, slab2 = z, None
+                    residual.bn_dx_done = True
+                elif slab is not None:       # dy arrived masked, its partial sums are in the slab
                     dz = _bn_backward_from_slab(bn, ctx, dy, z, z, slab, m)
                 else:
                     dz = bn.backward(ctx, dy, y.data if relu else None, z, z,   # dx overwrites z (dead after this)

@@ -22,7 +22,7 @@ def _hip():
 
 _TENSOR_OPS = [
     "conv_fprop", "conv_dgrad", "conv_wgrad", "transpose_krsc",
-    "bn_stats", "bn_finalize", "bn_eval_coeffs", "bn_apply", "bn_bwd_reduce", "bn_bwd_dx", "bn_bwd_from_slab",
+    "bn_stats", "bn_finalize", "bn_eval_coeffs", "bn_apply", "bn_bwd_reduce", "bn_bwd_dx", "bn_bwd_dx2", "bn_bwd_from_slab",
     "relu_fwd", "relu_bwd", "relu_bwd_colsum", "add", "copy", "dropout", "rng_advance", "colsum",
     "maxpool_fwd", "maxpool_bwd", "maxpool_bwd_bn", "avgpool_fwd", "avgpool_bwd",
     "ce_loss", "adam_step", "sgd_step", "advance_step", "cast", "augment_mnist",

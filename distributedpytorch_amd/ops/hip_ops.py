@@ -129,6 +129,16 @@ def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None, accumulate=Fals
     return dx
 
 
+def bn_bwd_dx2(dz, x1, coef1, dx1, x2, coef2, dx2):
+    """Two bn_bwd_dx (no mask) over one gradient dz in one pass: dx_i = A_i dz + B_i x_i + D_i."""
+    m, c, zcs = _mc(dz)
+    for t in (x1, dx1, x2, dx2):
+        assert _mc(t)[:2] == (m, c) and t.dtype == dz.dtype
+    _lib().dpa_bn_bwd_dx2(ptr(dz), zcs, ptr(x1), _mc(x1)[2], ptr(coef1), ptr(dx1), _mc(dx1)[2], ptr(x2), _mc(x2)[2], ptr(coef2),
+                          ptr(dx2), _mc(dx2)[2], I64(m), c, _DT[dz.dtype], stream_ptr())
+    return dx1, dx2
+
+
 # ----------------------------------------------------------------------------------------- elementwise
 def relu_fwd(x, y):
     m, c, xcs = _mc(x)

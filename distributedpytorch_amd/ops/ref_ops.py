@@ -239,6 +239,15 @@ def bn_bwd_dx(dz, x, coef, dx, mask_scale=None, mask_shift=None, accumulate=Fals
     return dx
 
 
+def bn_bwd_dx2(dz, x1, coef1, dx1, x2, coef2, dx2):
+    g = dz.float()
+    o1 = coef1[0] * g + coef1[1] * x1.float() + coef1[2]
+    o2 = coef2[0] * g + coef2[1] * x2.float() + coef2[2]
+    dx1.copy_(o1.to(dx1.dtype))
+    dx2.copy_(o2.to(dx2.dtype))
+    return dx1, dx2
+
+
 # ----------------------------------------------------------------------------------------- elementwise
 def relu_fwd(x, y):
     y.copy_(x.clamp_min(0))

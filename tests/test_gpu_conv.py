@@ -509,31 +509,38 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
         # the downsample blocks' compact gradients (nn/layers.py: Conv2d._dgrad) against full-resolution ones, and the ReLU
         # masks as bits (ConvBNAct) against the fused epilogues reading y itself: same bits in every gradient
         from distributedpytorch_amd.nn import layers
-        keep = layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2, layers._DEFER_DOWN_BN
+        keep = layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2, layers._DEFER_DOWN_BN, layers._BN_DX2
         try:
             res = {}
             for compact, relu_bits, bn2 in ((True, True, False), (False, True, False), (True, False, False), (True, True, True),
-                                            (True, True, "own_apply")):
+                                            (True, True, "own_apply"), (True, True, "two_dx")):
+                # "two_dx": second reduction fused, but bn3 and the downsample BatchNorm compute dx in separate passes
+                # (ops.bn_bwd_dx2 off): the same fp32 operations per element, so the same bits as (True, True, True)
+                layers._BN_DX2 = bn2 != "two_dx"
                 # "own_apply": the downsample branches apply their BatchNorm themselves instead of leaving it to the block's
                 # last bn_apply (ConvBNAct(defer_apply=True)): the same fp32 operations, so the same bits
                 layers._DEFER_DOWN_BN = bn2 != "own_apply"
-                layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = compact, relu_bits, bn2 is True
+                layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2 = compact, relu_bits, bn2 in (True, "two_dx")
                 torch.manual_seed(5)
                 net, _ = get_model("resnet50", 10, device="cuda", dtype=torch.float32)
-                made, with_bits, with_bn2 = [], [], []
-                orig = layers.ops.conv_dgrad
+                made, with_bits, with_bn2, dx2 = [], [], [], []
+                orig, orig_dx2 = layers.ops.conv_dgrad, layers.ops.bn_bwd_dx2
+
+                def spy_dx2(*a, **kw):
+                    dx2.append(1)
+                    return orig_dx2(*a, **kw)
 
                 def spy(*a, **kw):
                     made.append(kw.get("addend2") is not None)
                     with_bits.append(kw.get("bn_reduce") is not None and len(kw["bn_reduce"]) > 7)
                     with_bn2.append(kw.get("bn_reduce") is not None and len(kw["bn_reduce"]) > 8)
                     return orig(*a, **kw)
-                layers.ops.conv_dgrad = spy
+                layers.ops.conv_dgrad, layers.ops.bn_bwd_dx2 = spy, spy_dx2
                 try:
                     _, loss, _ = framework_step(net, x, y)
                 finally:
-                    layers.ops.conv_dgrad = orig
-                res[(compact, relu_bits, bn2)] = (loss, grads_by_name(net), sum(made), sum(with_bits), sum(with_bn2))
+                    layers.ops.conv_dgrad, layers.ops.bn_bwd_dx2 = orig, orig_dx2
+                res[(compact, relu_bits, bn2)] = (loss, grads_by_name(net), sum(made), sum(with_bits), sum(with_bn2), len(dx2))
             base = res[(True, True, False)]
             assert base[2] == 3 and res[(False, True, False)][2] == 0     # layer2.0, layer3.0, layer4.0 took a compact addend
             assert base[3] == 15 and res[(True, False, False)][3] == 0    # conv1 of every block after a residual ReLU read the bits
@@ -545,6 +552,10 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
             # summation order than bn_bwd_reduce's, so to rounding (see the docstring for what that means here)
             fused2 = res[(True, True, True)]
             assert fused2[4] == 4 and base[4] == 0
+            two_dx = res[(True, True, "two_dx")]
+            assert fused2[5] == 4 and two_dx[5] == 0 and two_dx[4] == 4 and two_dx[0] == fused2[0]
+            for k, gk in fused2[1].items():
+                assert torch.equal(two_dx[1][k], gk), ("two_dx", k)
             assert abs(fused2[0] - base[0]) < 1e-4 * max(1.0, abs(base[0]))
             ga = torch.cat([fused2[1][k].double().flatten() for k in base[1]])
             gb = torch.cat([g.double().flatten() for g in base[1].values()])
@@ -553,7 +564,7 @@ def test_resnet50_step_through_the_streaming_kernel(x6s_small):
                 if "downsample.1" in k:       # the BatchNorm parameters whose gradients ARE those sums
                     torch.testing.assert_close(fused2[1][k], base[1][k], rtol=2e-3, atol=1e-4 * gmax)
         finally:
-            layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2, layers._DEFER_DOWN_BN = keep
+            layers._COMPACT_DOWN, layers._RELU_BITS, layers._FUSE_BN2, layers._DEFER_DOWN_BN, layers._BN_DX2 = keep
     finally:
         lib.dpa_x6s_knob(1, 1)
         set_fp32_mode(prev)

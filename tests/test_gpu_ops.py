@@ -447,3 +447,23 @@ def test_maxpool_bwd_with_the_stem_batchnorm_reduction(shape, pad, dtype):
     mag = d.abs().sum((0, 1, 2)).max().item()
     assert (got[0] - want_s).abs().max().item() <= 1e-5 * mag
     assert (got[1] - want_q).abs().max().item() <= 3e-5 * mag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,c", [(1000, 64), (513, 256), (77, 2048)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_bn_bwd_dx_of_two_batchnorms_in_one_pass(m, c, dtype):
+    """bn_bwd_dx2 = two bn_bwd_dx launches over the same gradient, bit for bit (dx written over x, as the layers do)."""
+    from distributedpytorch_amd.ops import hip_ops
+    g = torch.Generator(device="cuda").manual_seed(m + c)
+    dz = torch.randn(m, 1, 1, c, device="cuda", generator=g).to(dtype)
+    x1 = torch.randn(m, 1, 1, c, device="cuda", generator=g).to(dtype)
+    x2 = torch.randn(m, 1, 1, c, device="cuda", generator=g).to(dtype)
+    c1 = torch.randn(3, c, device="cuda", generator=g)
+    c2 = torch.randn(3, c, device="cuda", generator=g)
+    w1, w2 = torch.empty_like(x1), torch.empty_like(x2)
+    hip_ops.bn_bwd_dx(dz, x1, c1, w1)
+    hip_ops.bn_bwd_dx(dz, x2, c2, w2)
+    a, b = x1.clone(), x2.clone()
+    hip_ops.bn_bwd_dx2(dz, a, c1, a, b, c2, b)
+    assert torch.equal(a, w1) and torch.equal(b, w2)
