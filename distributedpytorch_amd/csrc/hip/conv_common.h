@@ -51,8 +51,8 @@ struct ConvParams {
   const float* bnr_mscale;   // [dC] or null
   const float* bnr_mshift;   // [dC] or null
   float* bnr_slab;
-  const void* bnr_bits;      // or null: the ReLU mask as bits, [pixels][dC / 32] words (bn_apply_kernel) - kernels that know it
-                             // (conv_x6p.hip) read it INSTEAD of bnr_y: 1 / 32 of the bytes; the others use bnr_y
+  const void* bnr_bits;      // or null: the ReLU mask as bits, [pixels][dC / 32] words (bn_apply_kernel), read INSTEAD of
+                             // bnr_y: 1 / 32 of the bytes (dC % 32 == 0)
   // A SECOND BatchNorm whose output was added to the first one's before the ReLU (the downsample branch of a ResNet
   // block): same gradient, same mask, so sum dz is shared and the epilogue only adds sum dz * xhat2 over its input
   // bnr2_x: slab rows (sum dz, sum dz * xhat2) go to bnr2_slab.  Only conv_x6p.hip, and only together with bnr_bits
@@ -227,7 +227,11 @@ struct BnReduceLane {
   // v: the gradient values about to be stored for (pixel, col .. col + VEC); masked in place, sums updated
   __device__ __forceinline__ void visit(const ConvParams& p, size_t pixel, int col, float (&v)[VEC]) {
     Vec16<T> xv; xv.load(reinterpret_cast<const T*>(p.bnr_x) + pixel * (size_t)p.bnr_cs + col);
-    if (p.bnr_y) {
+    if (p.bnr_bits) {         // the mask as bits (dC % 32 == 0; VEC consecutive channels lie inside one word): y is not read
+      const uint32_t w = reinterpret_cast<const uint32_t*>(p.bnr_bits)[pixel * (size_t)(p.dC >> 5) + (size_t)(col >> 5)] >> (col & 31);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) if (!((w >> e) & 1u)) v[e] = 0.f;
+    } else if (p.bnr_y) {
       Vec16<T> yv; yv.load(reinterpret_cast<const T*>(p.bnr_y) + pixel * (size_t)p.bnr_y_cs + col);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) if (!(yv.get(e) > 0.f)) v[e] = 0.f;
@@ -238,6 +242,42 @@ struct BnReduceLane {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float d = v[e];
+      if (sizeof(T) == 2) d = bf2f(f2bf(d));     // sums of the values as stored
+      s[e] += d; q[e] += d * (xv.get(e) - mu[e]) * is[e];
+    }
+  }
+};
+
+// The same for conv_igemm.hip's epilogue, which prefetches its operands and has 168 registers (three blocks per CU): the
+// mask coefficients (used only when the mask comes from x, a path without a y / bits load) are read when needed instead
+// of living in 2 * VEC registers.  Same sums, same order as BnReduceLane::visit.
+template <typename T, int VEC>
+struct BnReduceLaneLite {
+  float s[VEC], q[VEC], mu[VEC], is[VEC];
+  __device__ __forceinline__ void init(const ConvParams& p, int col) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const bool ok = col + e < p.dC;
+      s[e] = 0.f; q[e] = 0.f;
+      mu[e] = ok ? p.bnr_mean[col + e] : 0.f; is[e] = ok ? p.bnr_invstd[col + e] : 0.f;
+    }
+  }
+  // x: the BatchNorm input; keep: bit e = the mask from y or the bits (have_mask), else from mscale * x + mshift > 0, else all
+  __device__ __forceinline__ void visit_loaded(const ConvParams& p, int col, bool have_mask, uint32_t keep_bits,
+                                               const Vec16<T>& xv, float (&v)[VEC]) {
+    if (!have_mask) {
+      keep_bits = ~0u;
+      if (p.bnr_mscale) {
+        keep_bits = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          keep_bits |= (xv.get(e) * p.bnr_mscale[col + e] + p.bnr_mshift[col + e] > 0.f ? 1u : 0u) << e;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float d = ((keep_bits >> e) & 1u) ? v[e] : 0.f;
+      v[e] = d;
       if (sizeof(T) == 2) d = bf2f(f2bf(d));     // sums of the values as stored
       s[e] += d; q[e] += d * (xv.get(e) - mu[e]) * is[e];
     }

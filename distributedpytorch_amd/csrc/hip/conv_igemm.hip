@@ -38,8 +38,12 @@ __device__ __forceinline__ void split3_bf16(const uint4& lo, const uint4& hi, ui
 // 3-way bf16 splits of the operands (p0q0 + p0q1 + p1q0 + p0q2 + p2q0 + p1q1, fp32 accumulation in the MFMA); the
 // dropped terms are below 2^-23 of the product, i.e. at the rounding of an fp32 multiply, and the bf16 matrix pipe
 // is 16x the fp32 one per MAC (6 x 16-cycle 16x16x32 MFMAs replace 8 x 32-cycle 16x16x4 ones per 32 k).
-template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false, bool X6 = false, bool UNI = false>
-__global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
+// BNR: a data-gradient launch with the fused BatchNorm-backward reduction (p.bnr_x != null).  An instantiation of its own:
+// its epilogue keeps a prefetched group of operands next to the reduction's per-channel state, which does not fit the 168
+// registers of three blocks per CU (these launches are bound by their epilogue's memory traffic, not by the K loop).
+template <typename T, int WM, int WN, int TM, int TN, bool DGRAD, bool GLDS, bool SPLIT = false, bool X6 = false, bool UNI = false,
+          bool BNR = false>
+__global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3)) conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte chunk
   constexpr int BKE = 8 * VEC;               // reduction elements per K-tile (128-byte rows)
@@ -402,8 +406,39 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
   }
   constexpr int LPR = WCOLS / VEC;             // lanes per output row (16-B chunks per row)
   constexpr int RPI = 64 / LPR;                // rows per store instruction
-  BnReduceLane<T, VEC> bnr;                    // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
-  if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + wn * WCOLS + (lane % LPR) * VEC); }
+  BnReduceLaneLite<T, VEC> bnr;                // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
+  if constexpr (BNR) bnr.init(p, n0 + wn * WCOLS + (lane % LPR) * VEC);
+  // The global operands of the epilogue (addend, BatchNorm input, mask) of the NEXT group of RPI rows are requested before
+  // the current group is consumed: one round trip to memory per group, 8 in a row per wave, was what bounded the fused
+  // data-gradient launches (2.9 TB/s).  (Two groups ahead does not fit the register budget of three blocks per CU.)
+  constexpr int NRR = 16 / RPI;
+  struct Pre { size_t off; Vec16<T> av, xv, yv; bool ok; };      // (yv.raw's first word holds the mask word when there are bits)
+  const uint32_t* __restrict__ mbits = BNR ? reinterpret_cast<const uint32_t*>(p.bnr_bits) : nullptr;
+  auto prefetch = [&](int k, Pre& t) __attribute__((always_inline)) {
+    const int i = k / NRR, q = k % NRR;
+    const int r = q * RPI + lane / LPR;
+    const int m = m0 + wm * TM * 16 + i * 16 + r;
+    const int col = n0 + wn * WCOLS + (lane % LPR) * VEC;
+    t.ok = m < p.M && col < p.dC;
+    if (!t.ok) return;
+    size_t pixel = (size_t)m;
+    if (DGRAD && (p.sh != 1 || p.sw != 1)) {      // class row -> (img, hi, wi) of the full gradient tensor
+      const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
+      const int jx = m - (int)t1 * p.cls_nw;
+      const uint32_t img = fd_div(t1, p.fd_nH);
+      const int iy = (int)t1 - (int)img * p.cls_nh;
+      pixel = ((size_t)img * p.dH + (size_t)(p.cls_h0 + p.sh * iy)) * p.dW + (size_t)(p.cls_w0 + p.sw * jx);
+    }
+    t.off = pixel * (size_t)p.d_cs + (size_t)(p.d_co + col);
+    if (addend) t.av.load(addend + t.off);
+    if constexpr (BNR) {
+      t.xv.load(reinterpret_cast<const T*>(p.bnr_x) + pixel * (size_t)p.bnr_cs + col);
+      if (mbits) *reinterpret_cast<uint32_t*>(&t.yv.raw) = mbits[pixel * (size_t)(p.dC >> 5) + (size_t)(col >> 5)] >> (col & 31);
+      else if (p.bnr_y) t.yv.load(reinterpret_cast<const T*>(p.bnr_y) + pixel * (size_t)p.bnr_y_cs + col);
+    }
+  };
+  Pre pre[2];
+  prefetch(0, pre[0]);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     // wave-private staging region: no block barrier needed between iterations, only LDS ordering
@@ -414,44 +449,45 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
         float v = acc[i][j][e] + bj[j];
         stage[(fq * 4 + e) * PITCH + j * 16 + fr] = v;
       }
-    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int rr = 0; rr < 16; rr += RPI) {
-      const int r = rr + lane / LPR;
+    for (int q = 0; q < NRR; ++q) {
+      const int k = i * NRR + q;
+      if (k + 1 < TM * NRR) prefetch(k + 1, pre[(k + 1) & 1]);
+      if (q == 0) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+      }
+      const int r = q * RPI + lane / LPR;
       const int cc = (lane % LPR) * VEC;
-      const int m = m0 + wm * TM * 16 + i * 16 + r;
-      const int col = n0 + wn * WCOLS + cc;
+      const Pre& t = pre[k & 1];
       float v[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; e += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc + e]);
-        v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+        const float4 f = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc + e]);
+        v[e] = f.x; v[e + 1] = f.y; v[e + 2] = f.z; v[e + 3] = f.w;
       }
-      if (m < p.M && col < p.dC) {
-        size_t pixel = (size_t)m;
-        if (DGRAD && (p.sh != 1 || p.sw != 1)) {      // class row -> (img, hi, wi) of the full gradient tensor
-          const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
-          const int jx = m - (int)t1 * p.cls_nw;
-          const uint32_t img = fd_div(t1, p.fd_nH);
-          const int iy = (int)t1 - (int)img * p.cls_nh;
-          pixel = ((size_t)img * p.dH + (size_t)(p.cls_h0 + p.sh * iy)) * p.dW + (size_t)(p.cls_w0 + p.sw * jx);
-        }
-        const size_t off = pixel * (size_t)p.d_cs + (size_t)(p.d_co + col);
+      if (t.ok) {
         if (addend) {
-          Vec16<T> av; av.load(addend + off);
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) v[e] += av.get(e);
+          for (int e = 0; e < VEC; ++e) v[e] += t.av.get(e);
         }
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if constexpr (DGRAD) { if (p.bnr_x) bnr.visit(p, pixel, col, v); }
+        if constexpr (BNR) {
+          uint32_t keep = *reinterpret_cast<const uint32_t*>(&t.yv.raw);
+          if (!mbits && p.bnr_y) {
+            keep = 0;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) keep |= (t.yv.get(e) > 0.f ? 1u : 0u) << e;
+          }
+          bnr.visit_loaded(p, n0 + wn * WCOLS + cc, mbits || p.bnr_y, keep, t.xv, v);
+        }
         Vec16<T> ov;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) ov.set(e, v[e]);
-        ov.store(dst + off);
+        ov.store(dst + t.off);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -502,8 +538,8 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6) ? 2 : 3)) conv_i
       if (n0 + col < p.dC) p.stats[((size_t)(p.stats_row0 + tm) * 2 + which) * p.dC + n0 + col] = s;
     }
   }
-  if constexpr (DGRAD) {
-    if (p.bnr_x) {       // lanes that share columns (lane % LPR) -> one value per wave, waves added in fixed order
+  if constexpr (BNR) {
+    {                    // lanes that share columns (lane % LPR) -> one value per wave, waves added in fixed order
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -693,27 +729,34 @@ static void launch_cfg(const ConvParams& pin, int dgrad, hipStream_t s) {
   } else if (sizeof(T) == 4 && fp32_x6() && (use_glds || (x6_reg() && WM != 4))) {   // (256 x 64 register-staged x6 would spill)
     if constexpr (sizeof(T) == 4) {
       if ((use_glds || WM == 4) && host_uni) {
-        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true, true>), grid, block, lds, s, p);
+        if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true, true, true>), grid, block, lds, s, p);
+        else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true, true>), grid, block, lds, s, p);
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true, true>), grid, block, lds, s, p);
       } else if (use_glds || WM == 4) {
-        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
+        if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true, false, true>), grid, block, lds, s, p);
+        else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, true>), grid, block, lds, s, p);
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, true>), grid, block, lds, s, p);
       } else if constexpr (WM != 4) {     // (not even instantiated for the 256 x 64 tile)
-        if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, true>), grid, block, lds, s, p);
+        if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, true, false, true>), grid, block, lds, s, p);
+        else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, true>), grid, block, lds, s, p);
         else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false, false, true>), grid, block, lds, s, p);
       }
     }
   } else if (use_glds && host_uni) {     // LDS-DMA staging, double-buffered, uniform-tap address path only (the usual case)
-    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, false, true>), grid, block, lds, s, p);
+    if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, false, true, true>), grid, block, lds, s, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, false, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true, false, false, true>), grid, block, lds, s, p);
   } else if (use_glds) {     // LDS-DMA staging, both address paths compiled in (stem, odd channel counts)
-    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
+    if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true, false, false, false, true>), grid, block, lds, s, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, true>), grid, block, lds, s, p);
   } else if (host_uni) {     // register staging, single buffer (short reductions), uniform-tap path only
-    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, false, true>), grid, block, lds, s, p);
+    if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, false, true, true>), grid, block, lds, s, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, false, true>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false, false, false, true>), grid, block, lds, s, p);
   } else {            // register staging, single buffer
-    if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false>), grid, block, lds, s, p);
+    if (dgrad && p.bnr_x) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false, false, false, false, true>), grid, block, lds, s, p);
+    else if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, true, false>), grid, block, lds, s, p);
     else       hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, TM, TN, false, false>), grid, block, lds, s, p);
   }
   if (p.splitK > 1) {

@@ -468,7 +468,7 @@ class ConvBNAct:
         # will complete this activation's gradient and mask it in its epilogue (Conv2d._bn_fusion)
         bits = None
         if (_RELU_BITS and relu and residual is not None and ctx.training and ctx.grad_enabled and needs and _FUSE_BN_BWD
-                and ctx.cuda and out.dtype == torch.float32 and cp % 32 == 0 and out.is_contiguous()):
+                and ctx.cuda and out.dtype in (torch.float32, torch.bfloat16) and cp % 32 == 0 and out.is_contiguous()):
             bits = ctx.empty((m, cp // 32), dtype=torch.int32)
         if not defer_apply:
             rs, rh = res_defer if res_defer is not None else (None, None)

@@ -356,7 +356,8 @@ def test_conv_dgrad_fused_bn_backward_reduce(shape, dtype, mask, fp32_mode, x6p_
             mean2 = torch.randn(C, device="cuda", generator=g) * 0.3 - 0.3
             invstd2 = torch.rand(C, device="cuda", generator=g) + 0.4
             second = (z2, mean2, invstd2, torch.full((rows, 2, C), float("nan"), device="cuda"))
-        reduce_args = (z, y if mask in ("y", "ybits") else None, mean, invstd,
+        # (with bits, the y handed over is the NEGATED one: a kernel that read it instead of the bits would mask the wrong half)
+        reduce_args = (z, (-y if mask == "ybits" else y) if mask in ("y", "ybits") else None, mean, invstd,
                        msc if mask == "x" else None, msh if mask == "x" else None, slab) \
             + ((_pack_mask_bits(y),) if mask == "ybits" else ())
         did_second = False
