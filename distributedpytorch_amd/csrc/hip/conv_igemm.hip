@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
   if constexpr (BNR) bnr.init(p, n0 + wn * WCOLS + (lane % LPR) * VEC);
   // The global operands of the epilogue (addend, BatchNorm input, mask) of the NEXT group of RPI rows are requested before
   // the current group is consumed: one round trip to memory per group, 8 in a row per wave, was what bounded the fused
-  // data-gradient launches (2.9 TB/s).  (Two groups ahead does not fit the register budget of three blocks per CU.)
+  // data-gradient launches (2.9 TB/s).
   constexpr int NRR = 16 / RPI;
   struct Pre { size_t off; Vec16<T> av, xv, yv; bool ok; };      // (yv.raw's first word holds the mask word when there are bits)
   const uint32_t* __restrict__ mbits = BNR ? reinterpret_cast<const uint32_t*>(p.bnr_bits) : nullptr;
@@ -437,8 +437,10 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
       else if (p.bnr_y) t.yv.load(reinterpret_cast<const T*>(p.bnr_y) + pixel * (size_t)p.bnr_y_cs + col);
     }
   };
-  Pre pre[2];
-  prefetch(0, pre[0]);
+  constexpr int PD = 1;                        // groups of look-ahead (3 in the BNR instantiations measured the same: 85.2 ms bf16 step)
+  Pre pre[PD + 1];
+#pragma unroll
+  for (int k = 0; k < PD && k < TM * NRR; ++k) prefetch(k, pre[k]);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     // wave-private staging region: no block barrier needed between iterations, only LDS ordering
@@ -452,14 +454,14 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
 #pragma unroll
     for (int q = 0; q < NRR; ++q) {
       const int k = i * NRR + q;
-      if (k + 1 < TM * NRR) prefetch(k + 1, pre[(k + 1) & 1]);
+      if (k + PD < TM * NRR) prefetch(k + PD, pre[(k + PD) % (PD + 1)]);
       if (q == 0) {
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();
       }
       const int r = q * RPI + lane / LPR;
       const int cc = (lane % LPR) * VEC;
-      const Pre& t = pre[k & 1];
+      const Pre& t = pre[k % (PD + 1)];
       float v[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; e += 4) {
