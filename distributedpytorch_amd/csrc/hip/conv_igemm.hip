@@ -521,16 +521,23 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
   }
   if (p.stats) {
     __syncthreads();                             // staging region is reused below (block-wide)
+    // All cross-lane sums first, a wait, then the LDS writes.  With a shuffle (ds_bpermute) issued right behind the
+    // masked ds_write of the previous column group - the natural loop - the bf16 register-staged instantiations wrote a
+    // wrong sum of squares for a few 16-column groups of a few tiles, differently from launch to launch (the second data
+    // register of the ds_write2 was the destination of the next ds_bpermute); scripts/diag/stats_race.py shows it.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float s = csum[j], q = csq[j];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (fq == 0) {
-        red[(wm * 2 + 0) * BN + wn * WCOLS + j * 16 + fr] = s;
-        red[(wm * 2 + 1) * BN + wn * WCOLS + j * 16 + fr] = q;
-      }
+      csum[j] += __shfl_xor(csum[j], 16, 64); csum[j] += __shfl_xor(csum[j], 32, 64);
+      csq[j] += __shfl_xor(csq[j], 16, 64); csq[j] += __shfl_xor(csq[j], 32, 64);
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (fq == 0) {
+        red[(wm * 2 + 0) * BN + wn * WCOLS + j * 16 + fr] = csum[j];
+        red[(wm * 2 + 1) * BN + wn * WCOLS + j * 16 + fr] = csq[j];
+      }
     __syncthreads();
     for (int c = tid; c < 2 * BN; c += 256) {
       const int which = c / BN, col = c - which * BN;
@@ -544,15 +551,18 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
     {                    // lanes that share columns (lane % LPR) -> one value per wave, waves added in fixed order
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float s = bnr.s[e], q = bnr.q[e];
+      for (int e = 0; e < VEC; ++e) {            // (shuffles, wait, then the writes: see the statistics above)
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (lane < LPR) {
-          red[(wm * 2 + 0) * BN + wn * WCOLS + lane * VEC + e] = s;
-          red[(wm * 2 + 1) * BN + wn * WCOLS + lane * VEC + e] = q;
-        }
+        for (int o = LPR; o < 64; o <<= 1) { bnr.s[e] += __shfl_xor(bnr.s[e], o, 64); bnr.q[e] += __shfl_xor(bnr.q[e], o, 64); }
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (lane < LPR) {
+          red[(wm * 2 + 0) * BN + wn * WCOLS + lane * VEC + e] = bnr.s[e];
+          red[(wm * 2 + 1) * BN + wn * WCOLS + lane * VEC + e] = bnr.q[e];
+        }
       __syncthreads();
       for (int c = tid; c < 2 * BN; c += 256) {
         const int which = c / BN, col = c - which * BN;
