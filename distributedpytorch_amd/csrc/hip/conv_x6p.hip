@@ -674,44 +674,57 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     }
     if (p.stats) {
       __syncthreads();                             // the staging region is reused below (block-wide)
+      // (every cross-lane sum, a wait, then the LDS writes - never a ds_bpermute right behind the masked ds_write of the
+      //  previous group: conv_igemm.hip's bf16 instantiations lost sums of squares that way, see its epilogue)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float s = csum[j], q = csq[j];
-        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-        if (fq == 0) {
-          red[(wave * 2 + 0) * BN + j * 16 + fr] = s;
-          red[(wave * 2 + 1) * BN + j * 16 + fr] = q;
-        }
+        csum[j] += __shfl_xor(csum[j], 16, 64); csum[j] += __shfl_xor(csum[j], 32, 64);
+        csq[j] += __shfl_xor(csq[j], 16, 64); csq[j] += __shfl_xor(csq[j], 32, 64);
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (fq == 0) {
+          red[(wave * 2 + 0) * BN + j * 16 + fr] = csum[j];
+          red[(wave * 2 + 1) * BN + j * 16 + fr] = csq[j];
+        }
       write_stats(p.stats, p.stats_row0);
     }
     if constexpr (DGRAD) {
       if (p.bnr_x) {
         __syncthreads();
+        float rs[4], rq[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float s = bnr.s[e], q = bnr.q[e];
+          rs[e] = bnr.s[e]; rq[e] = bnr.q[e];
 #pragma unroll
-          for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-          if (lane < LPR) {
-            red[(wave * 2 + 0) * BN + lane * 4 + e] = s;
-            red[(wave * 2 + 1) * BN + lane * 4 + e] = q;
-          }
+          for (int o = LPR; o < 64; o <<= 1) { rs[e] += __shfl_xor(rs[e], o, 64); rq[e] += __shfl_xor(rq[e], o, 64); }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (lane < LPR) {
+            red[(wave * 2 + 0) * BN + lane * 4 + e] = rs[e];
+            red[(wave * 2 + 1) * BN + lane * 4 + e] = rq[e];
+          }
         write_stats(p.bnr_slab, p.bnr_row0 + p.stats_row0);
         if (p.bnr2_x) {
           __syncthreads();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float s = bnr.s[e], q = q2[e];
+          for (int e = 0; e < 4; ++e) {              // (sum dz again: already reduced above)
 #pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-            if (lane < LPR) {
-              red[(wave * 2 + 0) * BN + lane * 4 + e] = s;
-              red[(wave * 2 + 1) * BN + lane * 4 + e] = q;
-            }
+            for (int o = LPR; o < 64; o <<= 1) q2[e] += __shfl_xor(q2[e], o, 64);
           }
+          __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (lane < LPR) {
+              red[(wave * 2 + 0) * BN + lane * 4 + e] = rs[e];
+              red[(wave * 2 + 1) * BN + lane * 4 + e] = q2[e];
+            }
           write_stats(p.bnr2_slab, p.bnr_row0 + p.stats_row0);
         }
       }

@@ -227,15 +227,18 @@ __global__ void __launch_bounds__(256, 2) conv_x6s_kernel(const ConvParams p, co
     float* red = reinterpret_cast<float*>(smem);           // [NW][2][BN] (an activation buffer: no DMA is in flight now)
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = csum[j], q = csq[j];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (fq == 0) {
-        red[(wave * 2 + 0) * BN + j * 16 + fr] = s;
-        red[(wave * 2 + 1) * BN + j * 16 + fr] = q;
-      }
+    for (int j = 0; j < TN; ++j) {                // (all shuffles, a wait, then the writes: see conv_igemm.hip's epilogue)
+      csum[j] += __shfl_xor(csum[j], 16, 64); csum[j] += __shfl_xor(csum[j], 32, 64);
+      csq[j] += __shfl_xor(csq[j], 16, 64); csq[j] += __shfl_xor(csq[j], 32, 64);
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (fq == 0) {
+        red[(wave * 2 + 0) * BN + j * 16 + fr] = csum[j];
+        red[(wave * 2 + 1) * BN + j * 16 + fr] = csq[j];
+      }
     __syncthreads();
     for (int c = tid; c < 2 * BN; c += NT) {
       const int which = c / BN, col = c - which * BN;

@@ -50,10 +50,18 @@ for r in range(nruns):
     torch.manual_seed(5)
     net, _ = get_model("resnet50", 1000, device="cuda", dtype=torch.float32 if len(sys.argv) > 4 and sys.argv[4] == "fp32" else torch.bfloat16)
     rec = []
-    framework_step(net, x, y)
+    _, loss, _ = framework_step(net, x, y)
     torch.cuda.synchronize()
+    from tests.helpers import grads_by_name
+    for k, gk in grads_by_name(net).items():      # (as records too: checksums in a dump, tensors in the in-process comparison)
+        rec.append(("grad " + k, gk.clone(), None))
+    rec.append(("loss", torch.tensor([loss], dtype=torch.float64), None))
     runs.append(rec)
     del net
+if len(sys.argv) > 5:        # cross-build comparison: dump run 0's slabs and output checksums, compare with compare_dumps()
+    torch.save([(a[0], a[1].double().sum().item(), a[1].double().abs().sum().item(), None if a[2] is None else a[2].cpu())
+                for a in runs[0]], sys.argv[5])
+    print("dumped", len(runs[0]), "records to", sys.argv[5])
 for r in range(1, nruns):
     for i, (a, b) in enumerate(zip(runs[0], runs[r])):
         same_out = torch.equal(a[1], b[1])
