@@ -521,10 +521,13 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
   }
   if (p.stats) {
     __syncthreads();                             // staging region is reused below (block-wide)
-    // All cross-lane sums first, a wait, then the LDS writes.  With a shuffle (ds_bpermute) issued right behind the
-    // masked ds_write of the previous column group - the natural loop - the bf16 register-staged instantiations wrote a
-    // wrong sum of squares for a few 16-column groups of a few tiles, differently from launch to launch (the second data
-    // register of the ds_write2 was the destination of the next ds_bpermute); scripts/diag/stats_race.py shows it.
+    // All cross-lane sums first, a wait, then the LDS writes.  With the natural loop (shuffle, masked ds_write2 of this
+    // column group, shuffle of the next group, ...) the bf16 register-staged instantiations wrote a sum of squares that
+    // was about one row's contribution short for a few 16-column groups of about one tile in 1500, differently from
+    // launch to launch (scripts/diag/stats_race.py: 39 of 39 launches differed; output bits and sums unaffected).  The
+    // mechanism was not isolated at the instruction level: this order removes it, and so does pinning the rounded value
+    // in a register before the packed multiply-add; a block barrier in front of the epilogue or a 256-register budget
+    // do not.  The regression test is tests/test_gpu_conv.py::test_fused_statistics_are_the_same_from_launch_to_launch.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       csum[j] += __shfl_xor(csum[j], 16, 64); csum[j] += __shfl_xor(csum[j], 32, 64);
