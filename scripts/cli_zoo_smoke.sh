@@ -18,7 +18,7 @@ for m in resnet alexnet vgg squeezenet densenet inception; do
      && DPA_SYNTHETIC_DATA=1 DPA_GPUS=0 DPA_COMPUTE_DTYPE=$DT DPA_MASTER_PORT=29641 PYTHONPATH=$ROOT timeout -k 10 300 python $ROOT/main.py test -d $W/data -b 50 -f rsl/bestmodel-mnist-$m.pt.tar > test.log 2>&1; then
     echo "$m $DT: $(grep -h 'Train  ' train.log | tail -1 | sed 's/ *| */ /g') | $(grep -h 'Acc:' test.log | tail -1)"
   else
-    echo "$m $DT: FAILED"; tail -5 train.log test.log 2>/dev/null; rc=1
+    echo "$m $DT: FAILED"; tail -5 train.log test.log 2>/dev/null; rm -rf $W; exit 1      # (nothing more on the GPU after a failed step)
   fi
 done
 rm -rf $W
