@@ -521,13 +521,16 @@ __global__ void __launch_bounds__(256, ((GLDS || WM == 4 || X6 || BNR) ? 2 : 3))
   }
   if (p.stats) {
     __syncthreads();                             // staging region is reused below (block-wide)
-    // All cross-lane sums first, a wait, then the LDS writes.  With the natural loop (shuffle, masked ds_write2 of this
-    // column group, shuffle of the next group, ...) the bf16 register-staged instantiations wrote a sum of squares that
-    // was about one row's contribution short for a few 16-column groups of about one tile in 1500, differently from
-    // launch to launch (scripts/diag/stats_race.py: 39 of 39 launches differed; output bits and sums unaffected).  The
-    // mechanism was not isolated at the instruction level: this order removes it, and so does pinning the rounded value
-    // in a register before the packed multiply-add; a block barrier in front of the epilogue or a 256-register budget
-    // do not.  The regression test is tests/test_gpu_conv.py::test_fused_statistics_are_the_same_from_launch_to_launch.
+    // All cross-lane sums first, a wait, then the (lane-masked) LDS writes.  With the natural loop - shuffles of column
+    // group j, `if (fq == 0)` LDS write, shuffles of group j + 1, ... - the bf16 register-staged instantiations wrote a
+    // sum of squares that was 1 ulp to 1 % off for a few 16-column groups of about one tile in 1500, differently from
+    // launch to launch (scripts/diag/stats_race.py: 39 of 39 launches differed; output bits and plain sums unaffected).
+    // A/B builds narrowed the trigger to the EXEC-masked write between the ds_bpermute pairs: the same loop with the write
+    // done by all lanes (they hold the same totals) is clean, as is this order; separate ds_write_b32 instead of a
+    // ds_write2, a wait after every write, a block barrier in front of the epilogue or a 256-register budget are not.
+    // The generated code around the mask (s_and_saveexec / ds_write2st64 / s_or exec / ds_bpermute) reads correct, so
+    // this is recorded as a hardware-level ordering effect between EXEC updates and ds_bpermute, avoided by construction.
+    // Regression test: tests/test_gpu_conv.py::test_fused_statistics_are_the_same_from_launch_to_launch.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       csum[j] += __shfl_xor(csum[j], 16, 64); csum[j] += __shfl_xor(csum[j], 32, 64);
