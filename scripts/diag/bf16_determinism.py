@@ -1,5 +1,5 @@
 """Is one bf16 ResNet-50 training step bit-reproducible at bench scale?  Two fresh models (same seed, same batch), one
-step each; lists the parameters whose gradients differ.  python scripts/diag/bf16_determinism.py [batch] [side] [dtype]"""
+step each; lists the parameters whose gradients differ.  python scripts/diag/bf16_determinism.py [batch] [side] [dtype] [model]"""
 import sys
 
 import torch
@@ -11,13 +11,14 @@ from tests.helpers import framework_step, grads_by_name            # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 side = int(sys.argv[2]) if len(sys.argv) > 2 else 224
 dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[sys.argv[3] if len(sys.argv) > 3 else "bf16"]
+model = sys.argv[4] if len(sys.argv) > 4 else "resnet50"
 torch.manual_seed(3)
 x = torch.randn(batch, 3, side, side)
 y = torch.randint(0, 1000, (batch,))
 runs = []
 for r in range(3):
     torch.manual_seed(5)
-    net, _ = get_model("resnet50", 1000, device="cuda", dtype=dtype)
+    net, _ = get_model(model, 1000, device="cuda", dtype=dtype)
     logits, loss, _ = framework_step(net, x, y)
     runs.append((logits.clone(), loss, {k: v.clone() for k, v in grads_by_name(net).items()}))
     del net
