@@ -283,8 +283,9 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
   constexpr int LPR = BN / 4;                  // lanes per output row (16-byte chunks)
   constexpr int RPI = 64 / LPR;                // rows per store instruction
 
-  BnReduceLane<float, 4> bnr;                  // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null)
-  if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + (lane % LPR) * 4); }
+  BnReduceLane<float, 4> bnr;                  // fused BatchNorm-backward reduction (dgrad, p.bnr_x != null); its 24 registers
+                                               // of per-channel state are filled at the START OF THE EPILOGUE, not here: they
+                                               // would be live across the whole K loop
   // the second BatchNorm of the same sum (conv_common.h: bnr2_x): sum dz * xhat2 (constants loaded at the epilogue's start)
   float q2[4] = {0.f, 0.f, 0.f, 0.f}, mu2[4] = {0.f, 0.f, 0.f, 0.f}, is2[4] = {0.f, 0.f, 0.f, 0.f};
   // 16 staged rows (block rows m0 + wave*WROWS + i*16 ..) -> global memory: addend, ReLU, dgrad pixel map, fused BN reduce.
@@ -629,6 +630,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     __syncthreads();
 
     // ---- epilogue: acc[i][j][e] = D[row = wave*WROWS + i*16 + fq*4 + e][col = j*16 + fr] ---------------------------------
+    if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + (lane % LPR) * 4); }
     if constexpr (RICH) {
       if (p.bnr2_x) {
 #pragma unroll
