@@ -170,11 +170,11 @@ template <int V> struct X6pInt { static constexpr int value = V; };
 // TMW = 1 ("short" tile, 64 x 64, round 3): for problems whose 128-row tiles would not fill ONE round of the chip's block
 // slots (small batches on 7x7 / 4x4 maps: ResNet-18 layer4 at batch 64 has 200 tiles for 512 slots) - twice the blocks,
 // three resident per CU; each activation fragment still feeds 4 filter fragments x 6 products.
-// RICH (dgrad): the epilogue features of the residual-block launches - compact addend (addend2), ReLU mask as bits, second
-// BatchNorm slab - compiled in.  Instantiations of their own: with those paths in every data-gradient kernel the plain and
+// RICH (dgrad): the epilogue features of the residual-block launches compiled in - 1: the ReLU mask as bits; 2: also the
+// compact addend (addend2) and the second BatchNorm slab.  Instantiations of their own: with those paths in every data-gradient kernel the plain and
 // singly-fused launches (35 of the 51 per ResNet-50 step) ran 5-6 % slower (register pressure around the K loop: 807 ->
 // 850 us average, profiles/r3_conv_layers_fp32_bs1024.txt).
-template <int TN, bool DGRAD, int NW, int MF, int TMW = 2, int ABL = 0, bool PIPE = false, bool RICH = false>
+template <int TN, bool DGRAD, int NW, int MF, int TMW = 2, int ABL = 0, bool PIPE = false, int RICH = 0>
 __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(const ConvParams p) {
   // ABL (diagnostic builds only, -DDPA_X6P_DIAG; results are WRONG, timing only): bit 0 = no operand split, bit 1 = no
   // LDS-DMA after the second K-tile, bit 2 = no MFMAs.
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
   // memory-bound 1x1 layers than the two-phase variant below (56x56 64->256 fprop: 1137 vs 1355 us)
   // compact addend (dgrad, p.addend2): the value for GEMM row m, columns col .. col + 3, or zeros for pixels with an odd
   // coordinate.  (img, hi, wi) of the full gradient tensor from the class row, as in the pixel map below.
-  const float* __restrict__ addend2 = RICH ? reinterpret_cast<const float*>(p.addend2) : nullptr;
+  const float* __restrict__ addend2 = RICH == 2 ? reinterpret_cast<const float*>(p.addend2) : nullptr;
   auto compact_addend = [&](int m, int col) __attribute__((always_inline)) {
     const uint32_t t1 = fd_div((uint32_t)m, p.fd_nW);
     const int jx = m - (int)t1 * p.cls_nw;
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
           const float4 a = *reinterpret_cast<const float4*>(addend + off);
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
-        if constexpr (RICH) {
+        if constexpr (RICH == 2) {
           if (addend2) { const float4 a = compact_addend(m, col); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
     // (the ReLU mask as bits when the producer made them: one word per 32 channels instead of 128 bytes of y)
     const float* __restrict__ by = bits ? nullptr : reinterpret_cast<const float*>(p.bnr_y);
     // (the second BatchNorm's input: only with the bit mask - its values live in the registers y would take)
-    const float* __restrict__ bx2 = (RICH && bits) ? reinterpret_cast<const float*>(p.bnr2_x) : nullptr;
+    const float* __restrict__ bx2 = (RICH == 2 && bits) ? reinterpret_cast<const float*>(p.bnr2_x) : nullptr;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int m = m0 + wave * WROWS + i * 16 + g * RPI + lane / LPR;
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
       pix[g] = pixel;
       off[g] = pixel * (size_t)p.d_cs + (size_t)(p.d_co + c_ok);
       if (addend) av[g] = *reinterpret_cast<const float4*>(addend + off[g]);
-      if constexpr (RICH) {         // (never together with a dense addend: conv_igemm.hip launch_conv)
+      if constexpr (RICH == 2) {    // (never together with a dense addend: conv_igemm.hip launch_conv)
         if (addend2) av[g] = ok[g] ? compact_addend(m, col) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (fuse) {
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
       const int r = g * RPI + lane / LPR;
       float4 v = *reinterpret_cast<const float4*>(&stage[r * PITCH + cc]);
       if (ok[g]) {
-        if (addend || (RICH && addend2)) { v.x += av[g].x; v.y += av[g].y; v.z += av[g].z; v.w += av[g].w; }
+        if (addend || (RICH == 2 && addend2)) { v.x += av[g].x; v.y += av[g].y; v.z += av[g].z; v.w += av[g].w; }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (fuse) {
           float a4[4] = {v.x, v.y, v.z, v.w};
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
             for (int e = 0; e < 4; ++e) y4[e] = (nib >> e) & 1u ? 1.f : 0.f;
           }
           bnr.visit_loaded(by != nullptr || bits != nullptr, x4, y4, a4);
-          if constexpr (RICH) {
+          if constexpr (RICH == 2) {
             if (bx2) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) q2[e] += a4[e] * (z2[e] - mu2[e]) * is2[e];
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
 
     // ---- epilogue: acc[i][j][e] = D[row = wave*WROWS + i*16 + fq*4 + e][col = j*16 + fr] ---------------------------------
     if constexpr (DGRAD) { if (p.bnr_x) bnr.init(p, n0 + (lane % LPR) * 4); }
-    if constexpr (RICH) {
+    if constexpr (RICH == 2) {
       if (p.bnr2_x) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(NW * 64, (TMW == 1 ? 3 : 2)) conv_x6p_kernel(c
             red[(wave * 2 + 1) * BN + lane * 4 + e] = rq[e];
           }
         write_stats(p.bnr_slab, p.bnr_row0 + p.stats_row0);
-        if (RICH && p.bnr2_x) {
+        if (RICH == 2 && p.bnr2_x) {
           __syncthreads();
 #pragma unroll
           for (int e = 0; e < 4; ++e) {              // (sum dz again: already reduced above)
@@ -749,7 +749,7 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   const size_t epi = (size_t)(NW * 16 * (BN + 4) + NW * 2 * BN) * 4;
   if (epi > lds) lds = epi;
   const dim3 grid(p.tilesM * p.tilesN), block(NW * 64);
-  const bool rich = dgrad && (p.addend2 || p.bnr_bits || p.bnr2_x);      // (see the template parameter)
+  const int rich = !dgrad ? 0 : ((p.addend2 || p.bnr2_x) ? 2 : (p.bnr_bits ? 1 : 0));      // (see the template parameter)
 #ifdef DPA_X6P_DIAG
   if constexpr (TN == 8 && TMW == 2) {
     const char* e = getenv("DPA_X6P_ABL");
@@ -768,13 +768,15 @@ static void x6p_launch(ConvParams& p, int dgrad, hipStream_t s) {
   if constexpr (TN == 8 && TMW == 2) {
     const int pipe_min = dpa_x6p_knob(3, -1);
     if (pipe_min > 0 && (p.Kg + 31) / 32 >= pipe_min) {
-      if (dgrad && rich) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, true, true>), grid, block, lds, s, p);
+      if (dgrad && rich == 2)      hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, true, 2>), grid, block, lds, s, p);
+      else if (dgrad && rich == 1) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, true, 1>), grid, block, lds, s, p);
       else if (dgrad)    hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, true>), grid, block, lds, s, p);
       else               hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW, 0, true>), grid, block, lds, s, p);
       return;
     }
   }
-  if (dgrad && rich) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, false, true>), grid, block, lds, s, p);
+  if (dgrad && rich == 2)      hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, false, 2>), grid, block, lds, s, p);
+  else if (dgrad && rich == 1) hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW, 0, false, 1>), grid, block, lds, s, p);
   else if (dgrad)    hipLaunchKernelGGL((conv_x6p_kernel<TN, true, NW, MF, TMW>), grid, block, lds, s, p);
   else               hipLaunchKernelGGL((conv_x6p_kernel<TN, false, NW, MF, TMW>), grid, block, lds, s, p);
 }

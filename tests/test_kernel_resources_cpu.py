@@ -58,15 +58,16 @@ def test_presplit_kernels_keep_their_residency_without_scratch(tmp_path):
     tile fits two waves per SIMD with no scratch."""
     res = {k: v for k, v in _resources(os.path.join(HIP_DIR, "conv_x6p.hip"), tmp_path).items() if "conv_x6p_kernel" in k}
     # six tiles with the plain double-buffered K loop + the software-pipelined loop of the wide tile (fprop, dgrad), and
-    # for every data-gradient instantiation a second one with the residual-block epilogue features (RICH)
+    # for every data-gradient instantiation two more with the residual-block epilogue features (RICH = 1: mask bits,
+    # RICH = 2: also the compact addend and the second BatchNorm slab)
     names = "\n".join(sorted(res))
-    assert len(res) == 12, f"expected the twelve production instantiations of conv_x6p_kernel, found {len(res)}:\n{names}"
-    assert sum(k.endswith("Lb1ELb0EEv10ConvParams") or k.endswith("Lb1ELb1EEv10ConvParams") for k in res) == 3, names   # PIPE
-    assert sum(k.endswith("Lb1EEv10ConvParams") for k in res) == 4, names                                              # RICH
+    assert len(res) == 16, f"expected the sixteen production instantiations of conv_x6p_kernel, found {len(res)}:\n{names}"
+    assert sum(re.search(r"Lb1ELi[012]EEv10ConvParams$", k) is not None for k in res) == 4, names            # PIPE
+    assert sum(re.search(r"ELi[12]EEv10ConvParams$", k) is not None for k in res) == 8, names                # RICH
     bad = {}
     for k, v in res.items():
         # template <TN, DGRAD, NW, MF, TMW, ABL, PIPE, RICH>: TMW == 1 is the 64 x 64 tile, built for three blocks per CU
-        short = re.search(r"ELi1ELi0ELb[01]ELb[01]EEv10ConvParams$", k) is not None
+        short = re.search(r"ELi1ELi0ELb[01]ELi[012]EEv10ConvParams$", k) is not None
         if v.get("ScratchSize", 0) != 0 or v.get("Occupancy", 0) < (3 if short else 2):
             bad[k] = v
     assert not bad, "\n".join(f"{k[:90]} {v}" for k, v in bad.items())
